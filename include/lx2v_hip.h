@@ -1,0 +1,115 @@
+/*
+ * lx2v_hip.h -- C ABI of liblx2v_hip.so: gfx950 (MI355X / CDNA4) kernels for the Wan DiT
+ * transformer-block forward.  Plain pointers and sizes only; every pointer is DEVICE memory
+ * unless noted.  Each entry point enqueues work on `stream` (a hipStream_t passed as void*;
+ * NULL = the legacy default stream), never synchronises, never allocates (unless stated), and
+ * returns 0 on success or a negative LX2V_E* code (lx2v_last_error() gives the text).
+ *
+ * bf16 tensors are raw 16-bit storage (uint16_t); scale/shift/gate/bias/norm-weight vectors
+ * and the RoPE table are fp32.  "ld*" arguments are row strides in ELEMENTS.
+ *
+ * The reference has no C ABI on this path: its boundary is a set of Python plugin classes.
+ * Each function below names the reference interface it stands behind (paths relative to the
+ * reference repository root).
+ */
+#ifndef LX2V_HIP_H
+#define LX2V_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LX2V_OK 0
+#define LX2V_EINVAL (-1)   /* shape / alignment / null-pointer precondition violated */
+#define LX2V_EUNSUP (-2)   /* valid request outside what the kernels are built for */
+#define LX2V_EHIP (-3)     /* a HIP runtime call failed (launch error) */
+
+/* ABI version of this header (bumped when a signature changes). */
+int lx2v_abi_version(void);
+/* Thread-local text of the last non-zero return. Host pointer, valid until the next call. */
+const char* lx2v_last_error(void);
+
+/* ---- LayerNorm (+ optional affine) (+ optional AdaLN modulate), one pass over HBM ----------
+ * out[r,:] = (LN(x[r,:]) * ln_w + ln_b) * (1 + scale) + shift       (fp32 statistics)
+ * ln_w/ln_b (both or neither) and scale/shift (both or neither) may be NULL.
+ * Replaces LNWeight.apply  lightx2v/common/ops/norm/layer_norm_weight.py:157-169
+ * fused with modulate      lightx2v/models/networks/wan/infer/transformer_infer.py:12-13
+ * (and fuse_scale_shift_kernel  lightx2v/models/networks/wan/infer/triton_ops.py:120-229).
+ * dim % 8 == 0, dim <= 8192. */
+int lx2v_ln_modulate_bf16(const uint16_t* x, int64_t ldx, const float* ln_w, const float* ln_b,
+                          const float* scale, const float* shift, uint16_t* out, int64_t ldo,
+                          int64_t rows, int dim, float eps, void* stream);
+
+/* ---- RMSNorm over the whole row (+ optional per-head interleaved-pair RoPE) ----------------
+ * y = x * rsqrt(mean(x^2) + eps) * w ; then for each head of `head_dim` columns and each pair
+ * i: (y[2i], y[2i+1]) *= (cos[r,i] + j sin[r,i]).  rope_cos_sin is fp32 [rows, head_dim]
+ * laid out cos(head_dim/2) || sin(head_dim/2) per row (the reference's flashinfer layout,
+ * lightx2v/models/schedulers/wan/scheduler.py:90-95), or NULL for no rotation.
+ * `w` may be NULL (rotation only; then no normalisation either when `do_norm` == 0).
+ * In-place allowed (out == x).
+ * Replaces RMSWeightSgl.apply  lightx2v/common/ops/norm/rms_norm_weight.py:131-146
+ * and apply_wan_rope_with_torch / _flashinfer
+ *                              lightx2v/models/networks/wan/infer/utils.py:12-28,64-87. */
+int lx2v_rmsnorm_rope_bf16(const uint16_t* x, int64_t ldx, const float* w, int do_norm,
+                           const float* rope_cos_sin, int head_dim, uint16_t* out, int64_t ldo,
+                           int64_t rows, int dim, float eps, void* stream);
+
+/* ---- x += y * gate (gate fp32 [dim] or NULL => x += y), in place on x ----------------------
+ * Replaces transformer_infer.py:209-213, 279, 312-316. */
+int lx2v_gate_residual_bf16(uint16_t* x, int64_t ldx, const uint16_t* y, int64_t ldy,
+                            const float* gate, int64_t rows, int dim, void* stream);
+
+/* ---- GELU (tanh approximation), elementwise -------------------------------------------------
+ * Replaces torch.nn.functional.gelu(approximate="tanh")  transformer_infer.py:305. */
+int lx2v_gelu_tanh_bf16(const uint16_t* x, uint16_t* out, int64_t n, void* stream);
+
+/* ---- Linear: C = epilogue(A @ W^T + bias) on MFMA ------------------------------------------
+ * A [M,K] (row stride lda), W [N,K] (the checkpoint's [out,in] layout, row stride ldw),
+ * bias fp32 [N] or NULL, C [M,N] (row stride ldc), fp32 accumulation.
+ *   epilogue LX2V_EPI_NONE      : C = acc + bias
+ *            LX2V_EPI_GELU_TANH : C = gelu_tanh(acc + bias)
+ *            LX2V_EPI_RESIDUAL  : C = resid + (acc + bias) * gate   (gate fp32 [N] or NULL => 1;
+ *                                  resid [M,N] row stride ldr; resid may alias C)
+ * A may be split along K into segments of a_kseg columns that sit a_kseg_stride ELEMENTS apart
+ * (segment s of row m starts at A + s*a_kseg_stride + m*lda); pass a_kseg = 0 for a plain
+ * matrix.  This lets the output projection read the sequence-parallel attention result
+ * [source_rank][S/N][H/N*d] without a gather copy.
+ * Requires K % 64 == 0, N % 16 == 0, 16-byte aligned rows.
+ * Replaces MMWeight.apply (torch.addmm)  lightx2v/common/ops/mm/mm_weight.py:163-170, with the
+ * residual/GELU steps of transformer_infer.py:209-213,279,305,312-316 fused as epilogues. */
+#define LX2V_EPI_NONE 0
+#define LX2V_EPI_GELU_TANH 1
+#define LX2V_EPI_RESIDUAL 2
+int lx2v_gemm_bf16(const uint16_t* A, int64_t lda, int64_t a_kseg, int64_t a_kseg_stride,
+                   const uint16_t* W, int64_t ldw, const float* bias,
+                   uint16_t* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
+                   const uint16_t* resid, int64_t ldr, const float* gate, void* stream);
+
+/* ---- Attention forward: out = softmax(q k^T * scale) v, non-causal, no mask, batch 1 --------
+ * q [sq, heads, head_dim], k/v [skv, heads, head_dim], out [sq, heads*head_dim]; token strides
+ * ld* in elements, heads are contiguous blocks of head_dim inside a token row.  head_dim must
+ * be 128.  Online softmax with fp32 statistics and fp32 accumulation on MFMA.
+ * If rope_cos_sin != NULL (fp32 [max(sq,skv), 128], cos||sin per row) the interleaved-pair
+ * rotation of lightx2v/models/networks/wan/infer/utils.py:12-28 is applied to q and k as they
+ * are loaded (requires sq == skv); pass NULL when q/k are already rotated.
+ * Replaces AttnWeightTemplate.apply: TorchSDPAWeight lightx2v/common/ops/attn/torch_sdpa.py:14-39,
+ * FlashAttn2Weight/FlashAttn3Weight lightx2v/common/ops/attn/flash_attn.py:29-96. */
+int lx2v_attn_fwd_bf16(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk,
+                       const uint16_t* v, int64_t ldv, uint16_t* out, int64_t ldo,
+                       int64_t sq, int64_t skv, int heads, int head_dim, float scale,
+                       const float* rope_cos_sin, void* stream);
+
+/* ---- Ulysses send-side pack: q,k,v [rows, heads*head_dim] -> [world][rows][3][heads/world*head_dim]
+ * so ONE all-to-all moves q, k and v and the receiver sees a uniform token stride.
+ * Replaces the three transpose().contiguous() packs of all2all_seq2head
+ * lightx2v/common/ops/attn/utils/all2all.py:29-33. */
+int lx2v_ulysses_pack_qkv_bf16(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk,
+                               const uint16_t* v, int64_t ldv, uint16_t* out, int64_t rows,
+                               int dim, int world, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LX2V_HIP_H */

@@ -1,0 +1,323 @@
+// Flash-style attention forward for gfx950, head_dim 128, bf16 in / bf16 out, non-causal.
+//
+// Workgroup = 8 waves = 256 query rows of one head (32 rows per wave); K/V tiles of 64 keys are
+// double-buffered in LDS (2 x (16 KiB K + 16 KiB V)), staged through registers: the global
+// loads of tile t+2 are issued while tile t is being consumed and are written to LDS one tile
+// later, so HBM/L2 latency hides under a full tile of MFMA work.
+//
+// Per wave and tile:
+//   S^T = K Q^T      v_mfma_f32_32x32x16_bf16, A = K rows (ds_read_b128 from an XOR-swizzled
+//                    [64][128] image), B = Q^T fragments held in registers for the whole kernel.
+//                    The result has the query row on the LANE and 32 of the 64 keys in the lane's
+//                    registers, so the row maximum / row sum are in-lane reductions plus one
+//                    half-wave exchange, and the per-row rescale is a per-lane multiply.
+//   online softmax   fp32: p = exp2(s*c - m*c), c = scale*log2(e); the rescale of O is skipped
+//                    (wave-uniform branch) on tiles where no row maximum grew.
+//   O^T += V^T P^T   the S^T accumulator registers, converted pairwise to bf16, ARE the B operand
+//                    (no LDS round trip, no shuffles); A = V^T fragments gathered with
+//                    ds_read_b64_tr_b16 from a [8 keys][32 cols] sub-tiled V image in the k order
+//                    the accumulator layout dictates (key = 16s + 8(j>>2) + 4h + (j&3)).
+// Optional fused 3-axis RoPE: q and k are rotated (interleaved pairs, fp32) as they are loaded.
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 128;       // head dim
+constexpr int QROWS = 256;    // query rows per workgroup
+constexpr int KVB = 64;       // keys per tile
+constexpr int NTHREADS = 512;
+constexpr int KV_TILE_BYTES = KVB * HD * 2;  // 16 KiB
+
+struct AttnParams {
+  const uint16_t* q;
+  const uint16_t* k;
+  const uint16_t* v;
+  uint16_t* out;
+  const float* rope;  // [tokens][128] cos(64) || sin(64), or null
+  int64_t ldq, ldk, ldv, ldo;
+  int sq, skv, heads, nqb;
+  float c;  // scale * log2(e)
+};
+
+LX2V_DEVICE int k_lds_off(int row, int ch) { return row * 256 + ((ch ^ (row & 15)) << 4); }
+LX2V_DEVICE int v_lds_off(int row, int ch) {
+  return 2048 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
+}
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+LX2V_DEVICE bf16x4 tr_read(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p));
+}
+
+// rotate the 4 interleaved pairs of one 8-element chunk: pairs pair0..pair0+3 of table row `cs`
+LX2V_DEVICE u32x4 rope_chunk(u32x4 v, const float* __restrict__ cs, int pair0) {
+  float f[8];
+  unpack8(v, f);
+  const f32x4 co = *reinterpret_cast<const f32x4*>(cs + pair0);
+  const f32x4 si = *reinterpret_cast<const f32x4*>(cs + 64 + pair0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = f[2 * i], b = f[2 * i + 1];
+    f[2 * i] = a * co[i] - b * si[i];
+    f[2 * i + 1] = a * si[i] + b * co[i];
+  }
+  return pack8(f);
+}
+
+LX2V_DEVICE float half_swap_max(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+LX2V_DEVICE float half_swap_sum(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+template <bool ROPE>
+__global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char lds[4 * KV_TILE_BYTES];  // [buf][K|V]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int r32 = lane & 31, h = lane >> 5;
+
+  const int qb = blockIdx.x % p.nqb;
+  const int head = blockIdx.x / p.nqb;
+  const int q0 = qb * QROWS + wid * 32;
+
+  // ---- Q^T fragments: lane holds Q[q0 + r32][16 ks + 8 h .. +7] for ks = 0..7 ----
+  bf16x8 qf[8];
+  {
+    const int qrow = min(q0 + r32, p.sq - 1);
+    const uint16_t* qp = p.q + (int64_t)qrow * p.ldq + head * HD + h * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(qp + ks * 16);
+      if (ROPE) v = rope_chunk(v, p.rope + (int64_t)qrow * HD, 8 * ks + 4 * h);
+      qf[ks] = __builtin_bit_cast(bf16x8, v);
+    }
+  }
+
+  // ---- K/V staging: thread owns chunks c = tid + 512 i (i = 0,1): row = c >> 4, ch = c & 15 ----
+  const int srow0 = tid >> 4, sch = tid & 15;  // second chunk: row + 32
+  const uint16_t* kbase = p.k + head * HD + sch * 8;
+  const uint16_t* vbase = p.v + head * HD + sch * 8;
+  int k_wr[2], v_wr[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    k_wr[i] = k_lds_off(srow0 + 32 * i, sch);
+    v_wr[i] = KV_TILE_BYTES + v_lds_off(srow0 + 32 * i, sch);
+  }
+  u32x4 kreg[2], vreg[2];
+  f32x4 rcos[2], rsin[2];  // only live when ROPE
+  // Loads only: nothing here may consume the loaded registers, or the wait for them would land
+  // at issue time instead of one tile later.
+  auto load_tile = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rc = min(t * KVB + srow0 + 32 * i, p.skv - 1);
+      kreg[i] = *reinterpret_cast<const u32x4*>(kbase + (int64_t)rc * p.ldk);
+      vreg[i] = *reinterpret_cast<const u32x4*>(vbase + (int64_t)rc * p.ldv);
+      if (ROPE) {
+        const float* cs = p.rope + (int64_t)rc * HD + 4 * sch;
+        rcos[i] = *reinterpret_cast<const f32x4*>(cs);
+        rsin[i] = *reinterpret_cast<const f32x4*>(cs + 64);
+      }
+    }
+  };
+  // Rotate (ROPE), zero rows past skv, write to LDS buffer `buf`.
+  auto write_tile = [&](int buf, int t) {
+    char* base = lds + buf * 2 * KV_TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      u32x4 kv = kreg[i], vv = vreg[i];
+      if (ROPE) {
+        float f[8];
+        unpack8(kv, f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a = f[2 * j], b = f[2 * j + 1];
+          f[2 * j] = a * rcos[i][j] - b * rsin[i][j];
+          f[2 * j + 1] = a * rsin[i][j] + b * rcos[i][j];
+        }
+        kv = pack8(f);
+      }
+      if (t * KVB + srow0 + 32 * i >= p.skv) {
+        kv = u32x4{0u, 0u, 0u, 0u};
+        vv = u32x4{0u, 0u, 0u, 0u};
+      }
+      *reinterpret_cast<u32x4*>(base + k_wr[i]) = kv;
+      *reinterpret_cast<u32x4*>(base + v_wr[i]) = vv;
+    }
+  };
+
+  // ---- fragment read offsets ----
+  // K (A operand of S^T): row = kb*32 + r32, chunk = 2 ks + h
+  int k_rd[2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) k_rd[kb] = (kb * 32 + r32) * 256;  // + ((2ks+h) ^ (row&15)) << 4, row&15 == r32&15
+  const int k_sw = r32 & 15;
+  // V^T (A operand of O^T): per 16-lane group g2 = (lane>>4)&1, lane-in-group li = lane & 15 -> q4 = li>>2, p4 = li&3
+  //   block rows r0 = 32 kb + 16 s + 8 u + 4 h (u = 0,1 -> elements 0..3 / 4..7), cols 32 db + 16 g2 .. +15
+  //   this lane supplies row r0 + q4, chunk c0 + (p4 >> 1) with c0 = 4 db + 2 g2, byte +8 (p4 & 1)
+  const int g2 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
+  int v_rd[4][2];  // [kstep = 2 kb + s][u]; db adds 512 * db (chunk >> 2 == db since c0 = 4 db + ...)
+#pragma unroll
+  for (int ks4 = 0; ks4 < 4; ++ks4)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int row = 16 * ks4 + 8 * u + 4 * h + q4;
+      const int chl = 2 * g2 + (p4 >> 1);  // chunk & 3
+      v_rd[ks4][u] = KV_TILE_BYTES + 2048 * (row >> 3) + 64 * (row & 7) + 16 * (chl ^ ((row >> 2) & 3)) + 8 * (p4 & 1);
+    }
+
+  f32x16 o[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  const int nt = (p.skv + KVB - 1) / KVB;
+  load_tile(0);
+  write_tile(0, 0);
+  if (nt > 1) load_tile(1);
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const char* kb_base = lds + (t & 1) * 2 * KV_TILE_BYTES;
+
+    // ---- S^T = K Q^T ----
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(kb_base + k_rd[kb] + (((2 * ks + h) ^ k_sw) << 4));
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s[kb], 0, 0, 0);
+      }
+    }
+
+    // ---- stage tile t+1 into the other buffer, issue the loads of tile t+2 ----
+    if (t + 1 < nt) {
+      write_tile((t + 1) & 1, t + 1);
+      if (t + 2 < nt) load_tile(t + 2);
+    }
+
+    // ---- mask keys past skv (last tile only) ----
+    if (t == nt - 1 && (p.skv & (KVB - 1)) != 0) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int key = t * KVB + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (key >= p.skv) s[kb][i] = -1e30f;
+        }
+    }
+
+    // ---- online softmax ----
+    float mx = s[0][0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[0][i]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[1][i]);
+    mx = half_swap_max(mx);
+    if (__any(mx > m_run)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.c);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+    }
+    const float mc = m_run * p.c;
+    bf16x8 pf[4];
+    float lsum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int sidx = 0; sidx < 2; ++sidx) {
+        bf16x8 f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float e = __builtin_amdgcn_exp2f(s[kb][8 * sidx + j] * p.c - mc);
+          lsum += e;
+          f[j] = (__bf16)e;
+        }
+        pf[kb * 2 + sidx] = f;
+      }
+    l_run += lsum;
+
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int ks4 = 0; ks4 < 4; ++ks4) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const bf16x4 lo = tr_read(kb_base + v_rd[ks4][0] + 512 * db);
+        const bf16x4 hi = tr_read(kb_base + v_rd[ks4][1] + 512 * db);
+        const bf16x8 a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf[ks4], o[db], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- normalise and store: o[db][i] = O[q0 + r32][32 db + 8 (i>>2) + 4 h + (i&3)] ----
+  const float inv = 1.0f / half_swap_sum(l_run);
+  const int qrow = q0 + r32;
+  if (qrow < p.sq) {
+    uint16_t* op = p.out + (int64_t)qrow * p.ldo + head * HD + 4 * h;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 pk = {pack2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv), pack2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv)};
+        *reinterpret_cast<u32x2*>(op + 32 * db + 8 * g) = pk;
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" int lx2v_attn_fwd_bf16(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk,
+                                  const uint16_t* v, int64_t ldv, uint16_t* out, int64_t ldo,
+                                  int64_t sq, int64_t skv, int heads, int head_dim, float scale,
+                                  const float* rope_cos_sin, void* stream) {
+  LX2V_REQUIRE(q && k && v && out, LX2V_EINVAL, "attn_fwd: null tensor");
+  LX2V_REQUIRE(head_dim == HD, LX2V_EUNSUP, "attn_fwd: head_dim=%d, only 128 is built", head_dim);
+  LX2V_REQUIRE(heads > 0 && sq >= 0 && skv >= 0, LX2V_EINVAL, "attn_fwd: bad shape sq=%lld skv=%lld heads=%d", (long long)sq, (long long)skv, heads);
+  LX2V_REQUIRE(sq < (1LL << 31) && skv < (1LL << 31), LX2V_EUNSUP, "attn_fwd: sequence lengths must fit in 31 bits");
+  LX2V_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, LX2V_EINVAL, "attn_fwd: token strides must be multiples of 8 elements");
+  LX2V_REQUIRE(ldq >= (int64_t)heads * HD && ldk >= (int64_t)heads * HD && ldv >= (int64_t)heads * HD && ldo >= (int64_t)heads * HD, LX2V_EINVAL,
+               "attn_fwd: token stride smaller than heads*head_dim");
+  LX2V_REQUIRE(lx2v_aligned16(q) && lx2v_aligned16(k) && lx2v_aligned16(v) && lx2v_aligned16(out), LX2V_EINVAL, "attn_fwd: tensors must be 16-byte aligned");
+  if (rope_cos_sin != nullptr) {
+    LX2V_REQUIRE(sq == skv, LX2V_EINVAL, "attn_fwd: fused RoPE needs sq == skv (self-attention)");
+    LX2V_REQUIRE(lx2v_aligned16(rope_cos_sin), LX2V_EINVAL, "attn_fwd: rope table must be 16-byte aligned");
+  }
+  if (sq == 0) return LX2V_OK;
+  LX2V_REQUIRE(skv > 0, LX2V_EINVAL, "attn_fwd: skv must be > 0 when sq > 0");
+  AttnParams p;
+  p.q = q; p.k = k; p.v = v; p.out = out; p.rope = rope_cos_sin;
+  p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+  p.sq = (int)sq; p.skv = (int)skv; p.heads = heads;
+  p.nqb = (int)((sq + QROWS - 1) / QROWS);
+  p.c = scale * 1.4426950408889634f;
+  const int64_t nwg = (int64_t)p.nqb * heads;
+  LX2V_REQUIRE(nwg < (1LL << 31), LX2V_EUNSUP, "attn_fwd: grid too large");
+  const dim3 grid((unsigned)nwg), block(NTHREADS);
+  if (rope_cos_sin != nullptr)
+    hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
+  LX2V_CHECK_LAUNCH("attn_fwd");
+  return LX2V_OK;
+}

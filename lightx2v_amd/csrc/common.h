@@ -1,0 +1,77 @@
+// Shared device helpers and host-side error plumbing for the gfx950 kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/lx2v_hip.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define LX2V_DEVICE __device__ __forceinline__
+
+// One 16-byte chunk = 8 bf16 values.
+LX2V_DEVICE void unpack8(const u32x4& v, float (&f)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(v[i] << 16);
+    f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+  }
+}
+
+LX2V_DEVICE uint32_t pack2(float lo, float hi) {
+  bf16x2 t;
+  t[0] = (__bf16)lo;  // round-to-nearest-even, NaN preserved (v_cvt_pk_bf16_f32)
+  t[1] = (__bf16)hi;
+  return __builtin_bit_cast(uint32_t, t);
+}
+
+LX2V_DEVICE u32x4 pack8(const float (&f)[8]) {
+  u32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = pack2(f[2 * i], f[2 * i + 1]);
+  return v;
+}
+
+LX2V_DEVICE float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+LX2V_DEVICE float gelu_tanh(float x) {
+  // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) written as x * sigmoid(2u)
+  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  return x / (1.0f + __expf(-2.0f * u));
+}
+
+// ---- host side -------------------------------------------------------------------------------
+void lx2v_set_error(const char* fmt, ...);
+
+#define LX2V_REQUIRE(cond, code, ...)  \
+  do {                                 \
+    if (!(cond)) {                     \
+      lx2v_set_error(__VA_ARGS__);     \
+      return (code);                   \
+    }                                  \
+  } while (0)
+
+#define LX2V_CHECK_LAUNCH(what)                                                   \
+  do {                                                                            \
+    hipError_t e__ = hipGetLastError();                                           \
+    if (e__ != hipSuccess) {                                                      \
+      lx2v_set_error("%s: launch failed: %s", what, hipGetErrorString(e__));      \
+      return LX2V_EHIP;                                                           \
+    }                                                                             \
+  } while (0)
+
+static inline bool lx2v_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -1,0 +1,252 @@
+// bf16 Linear on MFMA for gfx950: C[M,N] = epilogue(A[M,K] @ W[N,K]^T + bias).
+//
+// Both operands are K-contiguous (the checkpoint's [out,in] weight layout is exactly the
+// "B transposed" form MFMA wants), so A and W tiles are staged the same way.
+//
+// Tile: 256 x 256 x 64 per 512-thread workgroup (8 waves as 2(M) x 4(N), 128 x 64 per wave),
+// one workgroup per CU (128 KiB LDS: 2 stages x (A 32 KiB + W 32 KiB)).
+// Staging: LDS-DMA (global_load_lds, 16 B per lane).  The LDS image of a tile is [256 rows][8
+// chunks of 16 B]; the DMA writes lane-linear, so the bank-conflict swizzle
+// (chunk ^= (row >> 1) & 7) is applied to the per-lane SOURCE address and again on the read.
+// With it the 16 lanes of every ds_read_b128 lane group hit 16 distinct 16-B slots.
+// MFMA: v_mfma_f32_16x16x32_bf16 with the W fragment as the A operand, so each lane ends up
+// with 4 consecutive output columns of one row (8 contiguous bytes after packing).
+// Epilogue: bias / GELU / gate in fp32 on the accumulators, staged per wave through LDS as
+// bf16, then whole 128-B row segments are written (and the residual read) with 16-B accesses.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int NTHREADS = 512;
+constexpr int TILE_BYTES = BM * BK * 2;  // 32 KiB, same for A and W
+constexpr int GROUP_M = 8;               // tile rasterisation: 8 row-panels share one column sweep
+
+struct GemmParams {
+  const uint16_t* A;
+  const uint16_t* W;
+  const float* bias;
+  uint16_t* C;
+  const uint16_t* resid;
+  const float* gate;
+  int64_t lda, ldw, ldc, ldr;
+  int64_t a_kseg, a_kseg_stride;  // a_kseg == 0: plain matrix
+  int M, N, K;
+  int tiles_m, tiles_n;
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+LX2V_DEVICE void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)l, 16, 0, 0);
+}
+
+// Bijective remap so that blocks sharing an XCD (same blockIdx % 8) get a contiguous run of tiles.
+LX2V_DEVICE int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const GemmParams p) {
+  __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];  // [stage][A|W][32 KiB]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 2, wn = wid & 3;
+
+  // ---- tile coordinates (XCD-aware, grouped along M) ----
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int t = xcd_remap(blockIdx.x, nwg);
+  const int group_sz = GROUP_M * p.tiles_n;
+  const int g = t / group_sz;
+  const int first_m = g * GROUP_M;
+  const int gm = min(p.tiles_m - first_m, GROUP_M);
+  const int in_g = t - g * group_sz;
+  const int tile_m = first_m + in_g % gm;
+  const int tile_n = in_g / gm;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- per-thread staging sources: 4 DMA instructions per operand per K-tile ----
+  // LDS byte offset o = i*8192 + tid*16 -> row = o >> 7, physical chunk = (o >> 4) & 7.
+  const uint16_t* a_src[4];
+  const uint16_t* w_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int o = i * 8192 + tid * 16;
+    const int row = o >> 7;
+    const int chunk = ((o >> 4) & 7) ^ ((row >> 1) & 7);
+    const int ar = min(m0 + row, p.M - 1);
+    const int wr = min(n0 + row, p.N - 1);
+    a_src[i] = p.A + (int64_t)ar * p.lda + chunk * 8;
+    w_src[i] = p.W + (int64_t)wr * p.ldw + chunk * 8;
+  }
+  int64_t a_koff = 0;   // element offset of the current K-tile inside A (segment aware)
+  int64_t a_within = 0;
+
+  auto stage = [&](int s, int kt) {
+    char* la = lds + s * 2 * TILE_BYTES + wid * 1024;
+    char* lw = la + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(a_src[i] + a_koff, la + i * 8192);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(w_src[i] + (int64_t)kt * BK, lw + i * 8192);
+    // advance A's K offset to the next tile
+    a_koff += BK;
+    if (p.a_kseg != 0) {
+      a_within += BK;
+      if (a_within == p.a_kseg) {
+        a_within = 0;
+        a_koff += p.a_kseg_stride - p.a_kseg;
+      }
+    }
+  };
+
+  // ---- fragment read offsets ----
+  // A operand of the MFMA = W fragment: row n = wn*64 + nt*16 + (lane & 15), chunk = ks*4 + (lane >> 4)
+  // B operand of the MFMA = A fragment: row m = wm*128 + mt*16 + (lane & 15)
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_rd[2], w_rd[2];  // byte offsets for ks = 0,1 at mt/nt = 0 (rows step by 16 -> +2048 B, swizzle unchanged)
+  {
+    const int arow = wm * 128 + fr, wrow = wn * 64 + fr;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      a_rd[ks] = arow * 128 + (((ks * 4 + fq) ^ ((arow >> 1) & 7)) << 4);
+      w_rd[ks] = wrow * 128 + (((ks * 4 + fq) ^ ((wrow >> 1) & 7)) << 4);
+    }
+  }
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* la = lds + cur * 2 * TILE_BYTES;
+    const char* lw = la + TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[8], wf[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) wf[nt] = *reinterpret_cast<const bf16x8*>(lw + w_rd[ks] + nt * 2048);
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) af[mt] = *reinterpret_cast<const bf16x8*>(la + a_rd[ks] + mt * 2048);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue: fp32 math on accumulators -> per-wave LDS image (bf16) -> row stores ----
+  // acc[nt][mt][j] = C'[m = wm*128 + mt*16 + fr][n = wn*64 + nt*16 + fq*4 + j]
+  char* stg = lds + wid * 16384;  // 128 rows x 128 B per wave
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int ncol = n0 + wn * 64 + nt * 16 + fq * 4;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f}, gv = {1.f, 1.f, 1.f, 1.f};
+    if (ncol < p.N) {
+      if (p.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(p.bias + ncol);
+      if (EPI == LX2V_EPI_RESIDUAL && p.gate != nullptr) gv = *reinterpret_cast<const f32x4*>(p.gate + ncol);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = acc[nt][mt][j] + bv[j];
+        if (EPI == LX2V_EPI_GELU_TANH) v[j] = gelu_tanh(v[j]);
+        if (EPI == LX2V_EPI_RESIDUAL) v[j] *= gv[j];
+      }
+      const int r = mt * 16 + fr;                 // row inside the wave's 128-row image
+      const int slot = nt * 4 + fq;               // 8-byte slot inside the 128-B row
+      const int off = r * 128 + ((((slot >> 1) ^ (r & 7)) << 4) | ((slot & 1) << 3));
+      u32x2 pk = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+      *reinterpret_cast<u32x2*>(stg + off) = pk;
+    }
+  }
+  // Each wave reads back only its own image: a wave-level wait on the LDS writes is enough.
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  const int c8 = lane & 7;  // 16-B chunk inside the 128-B row segment
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int r = it * 8 + (lane >> 3);
+    const int gm_ = m0 + wm * 128 + r;
+    const int gn = n0 + wn * 64 + c8 * 8;
+    u32x4 val = *reinterpret_cast<const u32x4*>(stg + r * 128 + ((c8 ^ (r & 7)) << 4));
+    if (gm_ < p.M && gn < p.N) {
+      if (EPI == LX2V_EPI_RESIDUAL) {
+        float a[8], b[8];
+        unpack8(val, a);
+        unpack8(*reinterpret_cast<const u32x4*>(p.resid + (int64_t)gm_ * p.ldr + gn), b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += b[j];
+        val = pack8(a);
+      }
+      *reinterpret_cast<u32x4*>(p.C + (int64_t)gm_ * p.ldc + gn) = val;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int lx2v_gemm_bf16(const uint16_t* A, int64_t lda, int64_t a_kseg, int64_t a_kseg_stride,
+                              const uint16_t* W, int64_t ldw, const float* bias,
+                              uint16_t* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
+                              const uint16_t* resid, int64_t ldr, const float* gate, void* stream) {
+  LX2V_REQUIRE(A && W && C, LX2V_EINVAL, "gemm: null tensor");
+  LX2V_REQUIRE(M >= 0 && N > 0 && K > 0, LX2V_EINVAL, "gemm: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
+  LX2V_REQUIRE(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), LX2V_EUNSUP, "gemm: dimensions must fit in 31 bits");
+  LX2V_REQUIRE(K % BK == 0, LX2V_EUNSUP, "gemm: K=%lld must be a multiple of %d", (long long)K, BK);
+  LX2V_REQUIRE(N % 8 == 0, LX2V_EUNSUP, "gemm: N=%lld must be a multiple of 8", (long long)N);
+  LX2V_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0, LX2V_EINVAL, "gemm: row strides must be multiples of 8 elements");
+  LX2V_REQUIRE(ldw >= K && ldc >= N, LX2V_EINVAL, "gemm: ldw/ldc smaller than the row length");
+  LX2V_REQUIRE(lx2v_aligned16(A) && lx2v_aligned16(W) && lx2v_aligned16(C), LX2V_EINVAL, "gemm: tensors must be 16-byte aligned");
+  LX2V_REQUIRE(bias == nullptr || lx2v_aligned16(bias), LX2V_EINVAL, "gemm: bias must be 16-byte aligned");
+  if (a_kseg != 0) {
+    LX2V_REQUIRE(a_kseg > 0 && a_kseg % BK == 0 && K % a_kseg == 0, LX2V_EINVAL, "gemm: a_kseg=%lld must be a multiple of %d dividing K", (long long)a_kseg, BK);
+    LX2V_REQUIRE(a_kseg_stride % 8 == 0 && lda >= a_kseg, LX2V_EINVAL, "gemm: segmented A needs lda >= a_kseg and an 8-element aligned segment stride");
+  } else {
+    LX2V_REQUIRE(lda >= K, LX2V_EINVAL, "gemm: lda smaller than K");
+  }
+  LX2V_REQUIRE(epilogue == LX2V_EPI_NONE || epilogue == LX2V_EPI_GELU_TANH || epilogue == LX2V_EPI_RESIDUAL, LX2V_EINVAL, "gemm: unknown epilogue %d", epilogue);
+  if (epilogue == LX2V_EPI_RESIDUAL) {
+    LX2V_REQUIRE(resid != nullptr && ldr % 8 == 0 && ldr >= N && lx2v_aligned16(resid), LX2V_EINVAL, "gemm: residual epilogue needs an aligned resid with ldr >= N");
+    LX2V_REQUIRE(gate == nullptr || lx2v_aligned16(gate), LX2V_EINVAL, "gemm: gate must be 16-byte aligned");
+  }
+  if (M == 0) return LX2V_OK;
+
+  GemmParams p;
+  p.A = A; p.W = W; p.bias = bias; p.C = C; p.resid = resid; p.gate = gate;
+  p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
+  p.a_kseg = a_kseg; p.a_kseg_stride = a_kseg_stride;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  p.tiles_m = (int)((M + BM - 1) / BM);
+  p.tiles_n = (int)((N + BN - 1) / BN);
+  const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
+  LX2V_REQUIRE(nwg < (1LL << 31), LX2V_EUNSUP, "gemm: too many tiles");
+  const dim3 grid((unsigned)nwg), block(NTHREADS);
+  hipStream_t st = (hipStream_t)stream;
+  switch (epilogue) {
+    case LX2V_EPI_NONE: hipLaunchKernelGGL(gemm_bf16_kernel<LX2V_EPI_NONE>, grid, block, 0, st, p); break;
+    case LX2V_EPI_GELU_TANH: hipLaunchKernelGGL(gemm_bf16_kernel<LX2V_EPI_GELU_TANH>, grid, block, 0, st, p); break;
+    default: hipLaunchKernelGGL(gemm_bf16_kernel<LX2V_EPI_RESIDUAL>, grid, block, 0, st, p); break;
+  }
+  LX2V_CHECK_LAUNCH("gemm");
+  return LX2V_OK;
+}

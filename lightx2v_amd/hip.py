@@ -1,0 +1,216 @@
+"""ctypes binding of liblx2v_hip.so (the C ABI declared in include/lx2v_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, the op raises.
+Tensors are passed as raw device pointers; kernels are enqueued on torch's CURRENT stream
+(the reference's op classes do the same through torch, e.g. its offload path switches streams
+with `torch.cuda.stream(...)`, lightx2v/models/networks/wan/infer/offload/transformer_infer.py:65).
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_LIB_NAME = "liblx2v_hip.so"
+_lib: Optional[ctypes.CDLL] = None
+
+EPI_NONE, EPI_GELU_TANH, EPI_RESIDUAL = 0, 1, 2
+
+# name -> argtypes (restype is always c_int unless listed in _SPECIAL)
+_P, _I64, _I, _F = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+_SIGNATURES = {
+    "lx2v_ln_modulate_bf16": [_P, _I64, _P, _P, _P, _P, _P, _I64, _I64, _I, _F, _P],
+    "lx2v_rmsnorm_rope_bf16": [_P, _I64, _P, _I, _P, _I, _P, _I64, _I64, _I, _F, _P],
+    "lx2v_gate_residual_bf16": [_P, _I64, _P, _I64, _P, _I64, _I, _P],
+    "lx2v_gelu_tanh_bf16": [_P, _P, _I64, _P],
+    "lx2v_gemm_bf16": [_P, _I64, _I64, _I64, _P, _I64, _P, _P, _I64, _I64, _I64, _I64, _I, _P, _I64, _P, _P],
+    "lx2v_attn_fwd_bf16": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I, _I, _F, _P, _P],
+    "lx2v_ulysses_pack_qkv_bf16": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _I, _P],
+}
+EXPORTS = tuple(_SIGNATURES) + ("lx2v_abi_version", "lx2v_last_error")
+
+
+def lib_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+
+
+def load() -> ctypes.CDLL:
+    """Load the shared library once; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: build it with `make -C lightx2v_amd/csrc` (or __graft_entry__.build()). "
+            "lightx2v_amd has no CPU or PyTorch fallback for its ops."
+        )
+    lib = ctypes.CDLL(path)
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    lib.lx2v_abi_version.restype = ctypes.c_int
+    lib.lx2v_last_error.restype = ctypes.c_char_p
+    _lib = lib
+    return lib
+
+
+class Lx2vError(RuntimeError):
+    pass
+
+
+def _check(status: int, what: str):
+    if status != 0:
+        msg = load().lx2v_last_error().decode("utf-8", "replace")
+        raise Lx2vError(f"{what} failed with status {status}: {msg}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _need_bf16_cuda(name: str, t: torch.Tensor, inner_contig: bool = True):
+    if not t.is_cuda:
+        raise Lx2vError(f"{name}: expected a GPU tensor, got device {t.device} (no CPU fallback exists)")
+    if t.dtype != torch.bfloat16:
+        raise Lx2vError(f"{name}: expected bfloat16, got {t.dtype}")
+    if inner_contig and t.stride(-1) != 1:
+        raise Lx2vError(f"{name}: innermost dimension must be contiguous")
+
+
+def _vec_f32(name: str, t: Optional[torch.Tensor], n: int, like: torch.Tensor) -> Optional[torch.Tensor]:
+    """scale/shift/gate/bias/norm-weight vectors: any float dtype / shape with n elements -> fp32 [n]."""
+    if t is None:
+        return None
+    if t.numel() != n:
+        raise Lx2vError(f"{name}: expected {n} elements, got shape {tuple(t.shape)}")
+    v = t.reshape(n)
+    if v.dtype != torch.float32 or v.device != like.device or not v.is_contiguous():
+        v = v.to(device=like.device, dtype=torch.float32).contiguous()
+    return v
+
+
+# ---------------------------------------------------------------------------------------------
+def ln_modulate(x: torch.Tensor, ln_w=None, ln_b=None, scale=None, shift=None, eps: float = 1e-6,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _need_bf16_cuda("ln_modulate.x", x)
+    assert x.dim() == 2
+    rows, dim = x.shape
+    if out is None:
+        out = torch.empty((rows, dim), dtype=x.dtype, device=x.device)
+    w = _vec_f32("ln_w", ln_w, dim, x)
+    b = _vec_f32("ln_b", ln_b, dim, x)
+    sc = _vec_f32("scale", scale, dim, x)
+    sh = _vec_f32("shift", shift, dim, x)
+    st = load().lx2v_ln_modulate_bf16(x.data_ptr(), x.stride(0), _ptr(w), _ptr(b), _ptr(sc), _ptr(sh),
+                                       out.data_ptr(), out.stride(0), rows, dim, eps, _stream())
+    _check(st, "lx2v_ln_modulate_bf16")
+    return out
+
+
+def rmsnorm_rope(x: torch.Tensor, weight=None, rope_cos_sin: Optional[torch.Tensor] = None, head_dim: int = 128,
+                 eps: float = 1e-6, out: Optional[torch.Tensor] = None, do_norm: bool = True) -> torch.Tensor:
+    """x [rows, dim] (row stride free). rope_cos_sin fp32 [rows, head_dim] (cos || sin) or None."""
+    _need_bf16_cuda("rmsnorm_rope.x", x)
+    assert x.dim() == 2
+    rows, dim = x.shape
+    if out is None:
+        out = torch.empty((rows, dim), dtype=x.dtype, device=x.device)
+    w = _vec_f32("rms weight", weight, dim, x)
+    if rope_cos_sin is not None:
+        if rope_cos_sin.dtype != torch.float32 or not rope_cos_sin.is_contiguous() or tuple(rope_cos_sin.shape) != (rows, head_dim):
+            raise Lx2vError(f"rope table must be contiguous fp32 [{rows}, {head_dim}], got {tuple(rope_cos_sin.shape)} {rope_cos_sin.dtype}")
+    st = load().lx2v_rmsnorm_rope_bf16(x.data_ptr(), x.stride(0), _ptr(w), int(do_norm), _ptr(rope_cos_sin), head_dim,
+                                        out.data_ptr(), out.stride(0), rows, dim, eps, _stream())
+    _check(st, "lx2v_rmsnorm_rope_bf16")
+    return out
+
+
+def gate_residual_(x: torch.Tensor, y: torch.Tensor, gate=None) -> torch.Tensor:
+    _need_bf16_cuda("gate_residual.x", x)
+    _need_bf16_cuda("gate_residual.y", y)
+    assert x.shape == y.shape and x.dim() == 2
+    rows, dim = x.shape
+    g = _vec_f32("gate", gate, dim, x)
+    st = load().lx2v_gate_residual_bf16(x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), _ptr(g), rows, dim, _stream())
+    _check(st, "lx2v_gate_residual_bf16")
+    return x
+
+
+def gelu_tanh(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _need_bf16_cuda("gelu.x", x)
+    if not x.is_contiguous():
+        raise Lx2vError("gelu_tanh: input must be contiguous")
+    if out is None:
+        out = torch.empty_like(x)
+    st = load().lx2v_gelu_tanh_bf16(x.data_ptr(), out.data_ptr(), x.numel(), _stream())
+    _check(st, "lx2v_gelu_tanh_bf16")
+    return out
+
+
+def gemm(a: torch.Tensor, w_out_in: torch.Tensor, bias=None, epilogue: int = EPI_NONE, resid: Optional[torch.Tensor] = None,
+         gate=None, out: Optional[torch.Tensor] = None, a_kseg: int = 0, a_kseg_stride: int = 0, k_total: Optional[int] = None) -> torch.Tensor:
+    """C = epilogue(a @ w_out_in.T + bias).  a [M,K] bf16, w_out_in [N,K] bf16 (checkpoint layout)."""
+    _need_bf16_cuda("gemm.a", a)
+    _need_bf16_cuda("gemm.w", w_out_in)
+    assert a.dim() == 2 and w_out_in.dim() == 2
+    M = a.shape[0]
+    N, K = w_out_in.shape
+    if a_kseg == 0 and a.shape[1] != K:
+        raise Lx2vError(f"gemm: inner dimensions differ: a {tuple(a.shape)} vs w {tuple(w_out_in.shape)}")
+    if out is None:
+        out = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    b = _vec_f32("bias", bias, N, a)
+    g = _vec_f32("gate", gate, N, a)
+    if resid is not None:
+        _need_bf16_cuda("gemm.resid", resid)
+    st = load().lx2v_gemm_bf16(a.data_ptr(), a.stride(0), a_kseg, a_kseg_stride, w_out_in.data_ptr(), w_out_in.stride(0), _ptr(b),
+                               out.data_ptr(), out.stride(0), M, N, K, epilogue, _ptr(resid), 0 if resid is None else resid.stride(0),
+                               _ptr(g), _stream())
+    _check(st, "lx2v_gemm_bf16")
+    return out
+
+
+def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional[float] = None,
+             rope_cos_sin: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q [Sq,H,d], k/v [Skv,H,d] (token stride free, heads*d contiguous inside a token) -> [Sq, H*d]."""
+    for n, t in (("q", q), ("k", k), ("v", v)):
+        _need_bf16_cuda("attn." + n, t)
+        if t.dim() != 3 or t.stride(1) != t.shape[2]:
+            raise Lx2vError(f"attn.{n}: expected [S,H,d] with heads contiguous inside a token, got shape {tuple(t.shape)} strides {t.stride()}")
+    sq, H, d = q.shape
+    skv = k.shape[0]
+    if k.shape[1:] != (H, d) or v.shape != k.shape:
+        raise Lx2vError(f"attn: q {tuple(q.shape)} k {tuple(k.shape)} v {tuple(v.shape)} do not agree")
+    if scale is None:
+        scale = d ** -0.5
+    if out is None:
+        out = torch.empty((sq, H * d), dtype=q.dtype, device=q.device)
+    if rope_cos_sin is not None:
+        if rope_cos_sin.dtype != torch.float32 or not rope_cos_sin.is_contiguous() or tuple(rope_cos_sin.shape) != (sq, d):
+            raise Lx2vError(f"attn: rope table must be contiguous fp32 [{sq}, {d}]")
+    st = load().lx2v_attn_fwd_bf16(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
+                                   out.data_ptr(), out.stride(0), sq, skv, H, d, float(scale), _ptr(rope_cos_sin), _stream())
+    _check(st, "lx2v_attn_fwd_bf16")
+    return out
+
+
+def ulysses_pack_qkv(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, world: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q,k,v [rows, dim] -> [world, rows, 3, dim/world] (one all-to-all payload)."""
+    for n, t in (("q", q), ("k", k), ("v", v)):
+        _need_bf16_cuda("pack." + n, t)
+    rows, dim = q.shape
+    if out is None:
+        out = torch.empty((world, rows, 3, dim // world), dtype=q.dtype, device=q.device)
+    st = load().lx2v_ulysses_pack_qkv_bf16(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
+                                           out.data_ptr(), rows, dim, world, _stream())
+    _check(st, "lx2v_ulysses_pack_qkv_bf16")
+    return out

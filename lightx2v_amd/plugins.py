@@ -1,0 +1,343 @@
+"""HIP-backed op classes behind the reference's plugin surface.
+
+Every class keeps the constructor arguments, method names and return conventions of the
+reference class it stands in for, so a `WanTransformerInfer`-style caller that only uses
+`.load()` / `.apply()` / `.to_cuda()` / `.state_dict()` works unchanged:
+
+  ATTN_WEIGHT_REGISTER["hip_flash_attn"]  <-> FlashAttn2Weight / TorchSDPAWeight
+        (lightx2v/common/ops/attn/flash_attn.py:29-61, torch_sdpa.py:9-39)
+  ATTN_WEIGHT_REGISTER["hip_ulysses"]     <-> UlyssesAttnWeight (ulysses_attn.py:11-137)  [in ulysses.py]
+  MM_WEIGHT_REGISTER["hip-bf16"]          <-> MMWeight "Default" (lightx2v/common/ops/mm/mm_weight.py:119-201)
+  LN_WEIGHT_REGISTER["hip"]               <-> LNWeight "Default" (lightx2v/common/ops/norm/layer_norm_weight.py:135-169)
+  RMS_WEIGHT_REGISTER["hip"]              <-> RMSWeightSgl "sgl-kernel" (lightx2v/common/ops/norm/rms_norm_weight.py:112-146)
+  TENSOR_REGISTER["Default"]              <-> DefaultTensor (lightx2v/common/ops/tensor/tensor.py:9-78)
+
+All arithmetic runs in liblx2v_hip.so; there is no torch fallback (a CPU tensor raises).
+Extra `apply_*` methods expose the fused forms the block runner uses.
+"""
+
+from __future__ import annotations
+
+import re
+from typing import Optional
+
+import torch
+
+from . import hip
+from .registry_factory import (
+    ATTN_WEIGHT_REGISTER,
+    LN_WEIGHT_REGISTER,
+    MM_WEIGHT_REGISTER,
+    RMS_WEIGHT_REGISTER,
+    TENSOR_REGISTER,
+)
+
+COMPUTE_DTYPE = torch.bfloat16
+
+
+def _renumber(name: str, index: int) -> str:
+    """First `.N` in a checkpoint key -> `.index` (per-block buffer reuse, mm_weight.py:180-199)."""
+    return re.sub(r"\.\d+", lambda m: f".{index}", name, count=1)
+
+
+def _device_ready(t: Optional[torch.Tensor], dtype) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    return t.to(dtype=dtype).contiguous()
+
+
+# ----------------------------------------------------------------------------------- attention
+class _AttnBase:
+    """No-op weight plumbing every attention plugin inherits (attn/template.py:4-32)."""
+
+    def __init__(self):
+        self.config = {}
+
+    def load(self, weight_dict):
+        pass
+
+    def set_config(self, config=None):
+        if config is not None:
+            self.config = config
+
+    def to_cpu(self, non_blocking=False):
+        pass
+
+    def to_cuda(self, non_blocking=False):
+        pass
+
+    def state_dict(self, destination=None):
+        return {} if destination is None else destination
+
+    def load_state_dict(self, destination, block_index, adapter_block_index=None):
+        return {}
+
+
+@ATTN_WEIGHT_REGISTER("hip_flash_attn")
+class HipFlashAttnWeight(_AttnBase):
+    """softmax(q k^T / sqrt(d)) v on MFMA.  Non-causal, unmasked, one sequence (the only form the
+    Wan block uses: cu_seqlens = [0, S]).  `rope_cos_sin` (set by the caller before `apply`, fp32
+    [S, d] cos||sin) makes the kernel rotate q and k on load; it is consumed by one call."""
+
+    def __init__(self):
+        super().__init__()
+        self.rope_cos_sin: Optional[torch.Tensor] = None
+
+    def apply(self, q, k, v, drop_rate=0, attn_mask=None, causal=False, cu_seqlens_q=None, cu_seqlens_kv=None,
+              max_seqlen_q=None, max_seqlen_kv=None, model_cls=None):
+        if drop_rate not in (0, 0.0) or attn_mask is not None or causal:
+            raise NotImplementedError("hip_flash_attn: dropout, masks and causal attention are not part of the Wan block path")
+        if q.dim() == 4:  # [B,S,H,d] with B == 1 is flattened like flash_attn.py:47-51
+            if q.shape[0] != 1:
+                raise NotImplementedError("hip_flash_attn: batch > 1 is not part of the Wan block path")
+            q, k, v = q[0], k[0], v[0]
+        for name, cu, s in (("cu_seqlens_q", cu_seqlens_q, q.shape[0]), ("cu_seqlens_kv", cu_seqlens_kv, k.shape[0])):
+            if cu is not None and cu.numel() != 2:
+                raise NotImplementedError(f"hip_flash_attn: {name} must describe one sequence, got {cu.numel() - 1}")
+        rope, self.rope_cos_sin = self.rope_cos_sin, None
+        return hip.attn_fwd(q, k, v, rope_cos_sin=rope)
+
+
+# ----------------------------------------------------------------------------------- matmul
+@MM_WEIGHT_REGISTER("hip-bf16")
+class HipMMWeight:
+    """y = x W^T + b with the checkpoint's [out, in] weight used as stored (it is already the
+    K-contiguous operand MFMA wants; the reference keeps the same memory as a `.t()` view)."""
+
+    def __init__(self, weight_name, bias_name, create_cuda_buffer=False, lazy_load=False, lazy_load_file=None, is_post_adapter=False):
+        self.weight_name = weight_name
+        self.bias_name = bias_name
+        self.create_cuda_buffer = create_cuda_buffer
+        self.lazy_load = lazy_load
+        self.lazy_load_file = lazy_load_file
+        self.is_post_adapter = is_post_adapter
+        self.config = {}
+        self.weight_nk: Optional[torch.Tensor] = None  # [N, K] bf16
+        self.bias: Optional[torch.Tensor] = None       # [N] fp32
+
+    # -- reference-compatible views
+    @property
+    def weight(self):
+        return None if self.weight_nk is None else self.weight_nk.t()
+
+    def set_config(self, config={}):
+        self.config = config
+
+    def adopt(self, weight_nk: torch.Tensor, bias: Optional[torch.Tensor]):
+        """Use existing storage (e.g. a slice of a fused q|k|v weight) instead of copying."""
+        self.weight_nk = weight_nk
+        self.bias = bias
+
+    def load(self, weight_dict):
+        w = weight_dict[self.weight_name]
+        b = weight_dict[self.bias_name] if self.bias_name is not None else None
+        self.weight_nk = _device_ready(w, COMPUTE_DTYPE)
+        self.bias = _device_ready(b, torch.float32)
+        if self.create_cuda_buffer:
+            self.weight_cuda_buffer = self.weight_nk.cuda()
+            self.bias_cuda_buffer = None if self.bias is None else self.bias.cuda()
+
+    def _calculate_size(self):
+        n = self.weight_nk.numel() * self.weight_nk.element_size()
+        if self.bias is not None:
+            n += self.bias.numel() * self.bias.element_size()
+        return n
+
+    def to_cuda(self, non_blocking=False):
+        self.weight_nk = self.weight_nk.cuda(non_blocking=non_blocking)
+        if self.bias is not None:
+            self.bias = self.bias.cuda(non_blocking=non_blocking)
+
+    def to_cpu(self, non_blocking=False):
+        self.weight_nk = self.weight_nk.to("cpu", non_blocking=non_blocking)
+        if self.bias is not None:
+            self.bias = self.bias.to("cpu", non_blocking=non_blocking)
+
+    def state_dict(self, destination=None):
+        if destination is None:
+            destination = {}
+        destination[self.weight_name] = self.weight_nk
+        if self.bias_name is not None:
+            destination[self.bias_name] = self.bias
+        return destination
+
+    def load_state_dict(self, destination, block_index, adapter_block_index=None):
+        idx = adapter_block_index if self.is_post_adapter else block_index
+        assert idx is not None
+        wname = _renumber(self.weight_name, idx)
+        if wname not in destination:
+            self.weight_nk = None
+            return
+        self.weight_nk = self.weight_cuda_buffer.copy_(destination[wname], non_blocking=True)
+        if self.bias_name is not None:
+            self.bias = self.bias_cuda_buffer.copy_(destination[_renumber(self.bias_name, idx)], non_blocking=True)
+        else:
+            self.bias = None
+
+    # -- compute
+    def apply(self, input_tensor):
+        return hip.gemm(input_tensor, self.weight_nk, self.bias)
+
+    def apply_gelu(self, input_tensor):
+        return hip.gemm(input_tensor, self.weight_nk, self.bias, epilogue=hip.EPI_GELU_TANH)
+
+    def apply_residual_(self, input_tensor, resid, gate=None, a_kseg=0, a_kseg_stride=0):
+        """resid <- resid + (x W^T + b) * gate, in place; returns resid."""
+        return hip.gemm(input_tensor, self.weight_nk, self.bias, epilogue=hip.EPI_RESIDUAL, resid=resid, gate=gate, out=resid,
+                        a_kseg=a_kseg, a_kseg_stride=a_kseg_stride)
+
+
+# ----------------------------------------------------------------------------------- norms
+class _NormBase:
+    def __init__(self, create_cuda_buffer, lazy_load, lazy_load_file, is_post_adapter, eps):
+        self.create_cuda_buffer = create_cuda_buffer
+        self.lazy_load = lazy_load
+        self.lazy_load_file = lazy_load_file
+        self.is_post_adapter = is_post_adapter
+        self.eps = eps
+        self.config = {}
+
+    def set_config(self, config=None):
+        if config is not None:
+            self.config = config
+
+    def _names(self):
+        raise NotImplementedError
+
+    def _calculate_size(self):
+        return sum(t.numel() * t.element_size() for t in (getattr(self, a, None) for a in ("weight", "bias")) if t is not None)
+
+    def to_cuda(self, non_blocking=False):
+        for a in ("weight", "bias"):
+            t = getattr(self, a, None)
+            if t is not None:
+                setattr(self, a, t.cuda(non_blocking=non_blocking))
+
+    def to_cpu(self, non_blocking=False):
+        for a in ("weight", "bias"):
+            t = getattr(self, a, None)
+            if t is not None:
+                setattr(self, a, t.to("cpu", non_blocking=non_blocking))
+
+    def clear(self):
+        self.weight = None
+        if hasattr(self, "bias"):
+            self.bias = None
+
+
+@LN_WEIGHT_REGISTER("hip")
+class HipLNWeight(_NormBase):
+    """LayerNorm over the last dim, eps 1e-6, optional affine (norm3 has one, norm1/norm2 do not:
+    lightx2v/models/networks/wan/weights/transformer_weights.py:180-183,322-331,446-449)."""
+
+    def __init__(self, weight_name=None, bias_name=None, create_cuda_buffer=False, lazy_load=False, lazy_load_file=None,
+                 is_post_adapter=False, eps=1e-6):
+        super().__init__(create_cuda_buffer, lazy_load, lazy_load_file, is_post_adapter, eps)
+        self.weight_name = weight_name
+        self.bias_name = bias_name
+        self.weight = None
+        self.bias = None
+
+    def load(self, weight_dict):
+        if self.weight_name is not None:
+            self.weight = _device_ready(weight_dict[self.weight_name], torch.float32)
+            self.bias = _device_ready(weight_dict[self.bias_name], torch.float32) if self.bias_name is not None else torch.zeros_like(self.weight)
+
+    def state_dict(self, destination=None):
+        if destination is None:
+            destination = {}
+        if self.weight_name is not None:
+            destination[self.weight_name] = self.weight
+        if self.bias_name is not None:
+            destination[self.bias_name] = self.bias
+        return destination
+
+    def load_state_dict(self, destination, block_index, adapter_block_index=None):
+        idx = adapter_block_index if self.is_post_adapter else block_index
+        if self.weight_name is not None:
+            name = _renumber(self.weight_name, idx)
+            self.weight = destination.get(name)
+        if self.bias_name is not None and self.weight is not None:
+            self.bias = destination.get(_renumber(self.bias_name, idx))
+
+    def apply(self, input_tensor):
+        return hip.ln_modulate(input_tensor, self.weight, self.bias, eps=self.eps)
+
+    def apply_modulate(self, input_tensor, scale, shift):
+        """LN fused with `x * (1 + scale) + shift` (transformer_infer.py:12-13,154-157)."""
+        return hip.ln_modulate(input_tensor, self.weight, self.bias, scale, shift, eps=self.eps)
+
+
+@RMS_WEIGHT_REGISTER("hip")
+class HipRMSWeight(_NormBase):
+    """RMSNorm over the WHOLE last dim with fp32 statistics (what sgl_kernel.rmsnorm does for the
+    reference, rms_norm_weight.py:131-136); weight [dim]."""
+
+    def __init__(self, weight_name, create_cuda_buffer=False, lazy_load=False, lazy_load_file=None, is_post_adapter=False, eps=1e-6):
+        super().__init__(create_cuda_buffer, lazy_load, lazy_load_file, is_post_adapter, eps)
+        self.weight_name = weight_name
+        self.weight = None
+
+    def load(self, weight_dict):
+        self.weight = _device_ready(weight_dict[self.weight_name], torch.float32)
+
+    def state_dict(self, destination=None):
+        if destination is None:
+            destination = {}
+        destination[self.weight_name] = self.weight
+        return destination
+
+    def load_state_dict(self, destination, block_index, adapter_block_index=None):
+        idx = adapter_block_index if self.is_post_adapter else block_index
+        self.weight = destination.get(_renumber(self.weight_name, idx))
+
+    def apply(self, input_tensor):
+        shape = input_tensor.shape
+        x2 = input_tensor.reshape(-1, shape[-1])
+        return hip.rmsnorm_rope(x2, self.weight, None, eps=self.eps).view(shape)
+
+    def apply_rope_(self, x2d, rope_cos_sin, head_dim):
+        """In place: RMSNorm then per-head interleaved RoPE (one pass over HBM)."""
+        return hip.rmsnorm_rope(x2d, self.weight, rope_cos_sin, head_dim=head_dim, eps=self.eps, out=x2d)
+
+    def apply_(self, x2d):
+        return hip.rmsnorm_rope(x2d, self.weight, None, eps=self.eps, out=x2d)
+
+
+# ----------------------------------------------------------------------------------- tensors
+@TENSOR_REGISTER("Default")
+class DefaultTensor:
+    """Plain parameter holder (`modulation`, `head.modulation`)."""
+
+    def __init__(self, tensor_name, create_cuda_buffer=False, lazy_load=False, lazy_load_file=None, is_post_adapter=False):
+        self.tensor_name = tensor_name
+        self.create_cuda_buffer = create_cuda_buffer
+        self.lazy_load = lazy_load
+        self.lazy_load_file = lazy_load_file
+        self.is_post_adapter = is_post_adapter
+        self.tensor = None
+
+    def load(self, weight_dict):
+        self.tensor = weight_dict[self.tensor_name]
+
+    def clear(self):
+        self.tensor = None
+
+    def _calculate_size(self):
+        return self.tensor.numel() * self.tensor.element_size()
+
+    def to_cuda(self, non_blocking=False):
+        self.tensor = self.tensor.cuda(non_blocking=non_blocking)
+
+    def to_cpu(self, non_blocking=False):
+        self.tensor = self.tensor.to("cpu", non_blocking=non_blocking)
+
+    def state_dict(self, destination=None):
+        if destination is None:
+            destination = {}
+        destination[self.tensor_name] = self.tensor
+        return destination
+
+    def load_state_dict(self, destination, block_index, adapter_block_index=None):
+        idx = adapter_block_index if self.is_post_adapter else block_index
+        self.tensor = destination.get(_renumber(self.tensor_name, idx))

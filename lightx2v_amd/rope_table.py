@@ -1,0 +1,51 @@
+"""3-axis RoPE table for Wan latent grids, in the real (cos || sin) layout the HIP kernels read.
+
+Restates lightx2v/models/schedulers/wan/scheduler.py:31-48,77-114: head_dim/2 complex slots are
+split temporal | height | width as (c - 2(c//3), c//3, c//3); axis `a` with `n_a` slots uses
+theta = pos_a * 10000^(-2i/(2 n_a)), i = 0..n_a-1; tokens are ordered f-major, then h, then w; the
+same row serves every head.  Sequence-parallel ranks take contiguous chunks of the zero-padded
+table (zero cos AND sin, so padded tokens rotate to exactly 0, scheduler.py:96-113).
+"""
+
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+
+
+def axis_slots(head_dim: int) -> Tuple[int, int, int]:
+    c = head_dim // 2
+    return c - 2 * (c // 3), c // 3, c // 3
+
+
+def _axis_angles(n_pos: int, n_slots: int) -> torch.Tensor:
+    """fp32 [n_pos, n_slots] angles, evaluated in fp32 like the reference's `rope_params`."""
+    dim = 2 * n_slots
+    inv = 1.0 / torch.pow(torch.tensor(10000.0, dtype=torch.float32), torch.arange(0, dim, 2, dtype=torch.float32) / dim)
+    return torch.outer(torch.arange(n_pos, dtype=torch.float32), inv)
+
+
+def build_rope_table(grid: Tuple[int, int, int], head_dim: int = 128, device="cpu") -> torch.Tensor:
+    """fp32 [f*h*w, head_dim]: columns [0, head_dim/2) = cos, [head_dim/2, head_dim) = sin."""
+    f, h, w = grid
+    nt, nh, nw = axis_slots(head_dim)
+    at = _axis_angles(f, nt).view(f, 1, 1, nt).expand(f, h, w, nt)
+    ah = _axis_angles(h, nh).view(1, h, 1, nh).expand(f, h, w, nh)
+    aw = _axis_angles(w, nw).view(1, 1, w, nw).expand(f, h, w, nw)
+    ang = torch.cat([at, ah, aw], dim=-1).reshape(f * h * w, head_dim // 2)
+    return torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1).contiguous().to(device)
+
+
+def padded_len(seq_len: int, world_size: int) -> int:
+    return seq_len + (world_size - seq_len % world_size) % world_size
+
+
+def shard_rope_table(table: torch.Tensor, world_size: int, rank: int) -> torch.Tensor:
+    """Zero-pad rows to a multiple of world_size and return this rank's contiguous chunk."""
+    s = table.shape[0]
+    total = padded_len(s, world_size)
+    if total != s:
+        table = torch.cat([table, table.new_zeros(total - s, table.shape[1])], dim=0)
+    per = total // world_size
+    return table[rank * per:(rank + 1) * per].contiguous()

@@ -1,0 +1,105 @@
+"""Ulysses sequence parallelism over RCCL: head <-> sequence reshard around any attention plugin.
+
+Stands in for `UlyssesAttnWeight` (lightx2v/common/ops/attn/ulysses_attn.py:11-137) and its helpers
+`all2all_seq2head` / `all2all_head2seq` (lightx2v/common/ops/attn/utils/all2all.py:7-89) with the
+same result -- global token order is rank-major chunks, rank r attends heads r*H/N..(r+1)*H/N,
+output heads are ordered by source rank -- and a different data path:
+
+  * q, k and v travel in ONE all-to-all (the reference issues three).  The send buffer is
+    [dest rank][S/N][q|k|v][H/N*d], written by one pack kernel, so on arrival token (src, s) of
+    tensor `which` sits at ((src*S/N + s)*3 + which)*H/N*d: a uniform token stride of 3*H/N*d that
+    the attention kernel reads in place (no transpose/contiguous copies on either side).
+  * The attention output [S, H/N*d] is already the send layout of the return all-to-all.
+  * The receive buffer [src rank][S/N][H/N*d] can be handed to the output projection as a
+    K-segmented operand (`apply_segmented`), which removes the final gather copy too.
+
+On MI355X every GPU pair has its own xGMI link, so an all-to-all drives all 7 links at once;
+`torch.distributed` backend "nccl" is RCCL on ROCm.
+"""
+
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import hip
+from .plugins import _AttnBase
+from .registry_factory import ATTN_WEIGHT_REGISTER
+
+
+@ATTN_WEIGHT_REGISTER("hip_ulysses")
+class HipUlyssesAttnWeight(_AttnBase):
+    def __init__(self, pack_fn: Optional[Callable] = None):
+        """`pack_fn(q2d, k2d, v2d, world) -> [world, rows, 3, dim/world]`; defaults to the HIP pack
+        kernel.  (Injectable so the exchange logic can be exercised with host tensors in tests.)"""
+        super().__init__()
+        self._pack = pack_fn or hip.ulysses_pack_qkv
+
+    # ---- exchange core -------------------------------------------------------------------------
+    def _exchange_attend(self, q, k, v, attention_module, group, model_cls=None) -> Tuple[torch.Tensor, int, int, int]:
+        if q.dim() == 4:
+            q, k, v = (t.reshape(-1, t.shape[-2], t.shape[-1]) for t in (q, k, v))
+        world = dist.get_world_size(group)
+        sl, heads, d = q.shape
+        if heads % world != 0:
+            raise ValueError(f"hip_ulysses: num_heads={heads} is not divisible by the sequence-parallel size {world}")
+        hs = heads // world
+        dim = heads * d
+        send = self._pack(q.reshape(sl, dim), k.reshape(sl, dim), v.reshape(sl, dim), world)  # [world, sl, 3, hs*d]
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=group)
+        r = recv.view(world * sl, 3, hs, d)
+        attn = attention_module.apply(q=r[:, 0], k=r[:, 1], v=r[:, 2], cu_seqlens_q=None, cu_seqlens_kv=None,
+                                      max_seqlen_q=world * sl, max_seqlen_kv=world * sl, model_cls=model_cls)  # [S, hs*d]
+        back = torch.empty_like(attn)
+        dist.all_to_all_single(back, attn.contiguous(), group=group)  # [src][sl][hs*d]
+        return back, world, sl, hs * d
+
+    # ---- reference-compatible entry ------------------------------------------------------------
+    def apply(self, q, k, v, img_qkv_len, cu_seqlens_qkv, attention_module=None, seq_p_group=None, model_cls=None, use_fp8_comm=False):
+        """q,k,v [S/N, H, d] -> [S/N, H*d] (ulysses_attn.py:16)."""
+        if use_fp8_comm:
+            raise NotImplementedError("hip_ulysses: fp8 payload exchange is not built yet")
+        if int(cu_seqlens_qkv[-1]) != int(img_qkv_len) or q.shape[0] != img_qkv_len:
+            raise NotImplementedError("hip_ulysses: a text part after the image tokens (HunyuanVideo layout) is not built yet")
+        back, world, sl, seg = self._exchange_attend(q, k, v, attention_module, seq_p_group, model_cls)
+        return back.view(world, sl, seg).permute(1, 0, 2).reshape(sl, world * seg)
+
+    # ---- zero-copy form for the fused block runner ---------------------------------------------
+    def apply_segmented(self, q, k, v, attention_module=None, seq_p_group=None, model_cls=None):
+        """Returns (buffer, a_kseg, a_kseg_stride): logical [S/N, H*d] matrix whose K columns
+        [src*seg, (src+1)*seg) live at buffer + src*a_kseg_stride + row*seg."""
+        back, world, sl, seg = self._exchange_attend(q, k, v, attention_module, seq_p_group, model_cls)
+        return back.view(world * sl, seg)[:sl], seg, sl * seg
+
+
+def make_groups(cfg_p_size: int, seq_p_size: int):
+    """2-D layout (cfg_p, seq_p) with seq_p the fast (contiguous-rank) dimension, as
+    lightx2v/utils/set_config.py:90-105 builds it.  Returns (cfg_index, seq_index, seq_group, cfg_group);
+    every rank creates every group (collective requirement of `new_group`)."""
+    world = dist.get_world_size()
+    rank = dist.get_rank()
+    if cfg_p_size * seq_p_size != world:
+        raise ValueError(f"cfg_p_size*seq_p_size = {cfg_p_size * seq_p_size} != world size {world}")
+    cfg_idx, seq_idx = divmod(rank, seq_p_size)
+    seq_group = cfg_group = None
+    for c in range(cfg_p_size):
+        g = dist.new_group(ranks=[c * seq_p_size + s for s in range(seq_p_size)])
+        if c == cfg_idx:
+            seq_group = g
+    for s in range(seq_p_size):
+        g = dist.new_group(ranks=[c * seq_p_size + s for c in range(cfg_p_size)])
+        if s == seq_idx:
+            cfg_group = g
+    return cfg_idx, seq_idx, seq_group, cfg_group
+
+
+def cfg_parallel_combine(noise_pred_local: torch.Tensor, cfg_group, guide_scale: float) -> torch.Tensor:
+    """CFG split over 2 ranks (lightx2v/models/networks/wan/model.py:412-433): rank 0 of the group ran
+    the conditional pass, rank 1 the unconditional one; one all_gather, then u + g (c - u)."""
+    parts = [torch.empty_like(noise_pred_local) for _ in range(2)]
+    dist.all_gather(parts, noise_pred_local.contiguous(), group=cfg_group)
+    cond, uncond = parts
+    return uncond + guide_scale * (cond - uncond)

@@ -1,0 +1,103 @@
+"""The whole block (and head) on the GPU against the reference's golden vectors and the CPU oracle.
+
+Tolerance: the north star asks per-block output cosine >= 0.999 against the fp32 torch_sdpa path.
+The reference's own all-bf16 block measures 0.999995 on outputs and 0.99964 on the block DELTA
+(out - in); this build keeps statistics/accumulators in fp32 and is held to >= 0.9995 on the delta."""
+import pytest
+import torch
+
+import lightx2v_amd as L
+from oracle import wan_block_ref as R
+from tests.util import BLOCK_CASES, case_inputs, cos, golden_rows, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(c, cuda, n_layers=1, **cfg_kw):
+    cfg = {"num_layers": n_layers, "num_heads": c["heads"], "dim": c["dim"], "task": "t2v"}
+    cfg.update(cfg_kw)
+    W = L.WanTransformerWeights(cfg)
+    wd = dict(c["w"])
+    wd.update(c["hw"])
+    W.load(wd)
+    W.to_cuda()
+    inf = L.WanTransformerInfer(cfg)
+    inf.cos_sin = R.cos_sin_to_real(c["cos_sin"]).contiguous().to(cuda)
+    return W, inf
+
+
+def _pre(c, cuda):
+    return L.WanPreInferModuleOutput(embed=c["embed"].to(cuda), grid_sizes=c["grid"], x=c["x"].to(torch.bfloat16).to(cuda),
+                                     embed0=c["embed0"].to(cuda), context=c["context"].to(torch.bfloat16).to(cuda))
+
+
+@pytest.mark.parametrize("name", BLOCK_CASES)
+@pytest.mark.parametrize("mode", ["fused", "op_by_op", "rope_in_attn"])
+def test_block_vs_reference_golden(cuda, name, mode):
+    rec = load_golden(name)
+    c = case_inputs(rec)
+    kw = {"fused": {}, "op_by_op": {"fused_block": False}, "rope_in_attn": {"rope_type": "hip_attn"}}[mode]
+    W, inf = _build(c, cuda, **kw)
+    pre = _pre(c, cuda)
+    x_in = pre.x.clone()
+    out = inf.infer_block(W.blocks[0], pre.x, pre)
+    assert out.data_ptr() == pre.x.data_ptr()  # in-place residual stream like the reference
+    rows = golden_rows(rec, c["S"])
+    ref = torch.from_numpy(rec["x_out"])
+    got = out.float().cpu()[rows]
+    delta_ref = ref - c["x"][rows]
+    delta_got = got - x_in.float().cpu()[rows]
+    assert cos(got, ref) >= 0.9999, cos(got, ref)
+    assert cos(delta_got, delta_ref) >= 0.9995, cos(delta_got, delta_ref)
+    assert (got - ref).abs().max().item() <= 0.06 * max(1.0, ref.abs().max().item() / 4)
+
+
+@pytest.mark.parametrize("name", ["tiny_d256_g3x6x8", "wan1p3b_g3x6x8"])
+def test_head_vs_reference_golden(cuda, name):
+    rec = load_golden(name)
+    c = case_inputs(rec)
+    W, inf = _build(c, cuda)
+    x_full = R.block_forward(c["x"], c["embed0"], c["context"], c["w"], c["cos_sin"], c["heads"])
+    out = inf.infer_non_blocks(W, x_full.to(torch.bfloat16).to(cuda), c["embed"].to(cuda))
+    rows = golden_rows(rec, c["S"])
+    ref = torch.from_numpy(rec["head_out"])
+    assert out.shape == (c["S"], 64)
+    assert cos(out.float().cpu()[rows], ref) >= 0.9995
+
+
+def test_stagewise_cosines_1p3b(cuda):
+    """Per-stage cosines (attention out, cross-attention out, FFN out) at 1.3B dims, S=4680."""
+    rec = load_golden("wan1p3b_g3x30x52")
+    c = case_inputs(rec)
+    W, inf = _build(c, cuda, fused_block=False)
+    sa, ca, ff = W.blocks[0].compute_phases
+    pre = _pre(c, cuda)
+    shift, scale, gate, c_shift, c_scale, c_gate = inf.pre_process(sa.modulation, pre.embed0)
+    rows = golden_rows(rec, c["S"])
+    y = inf.infer_self_attn(sa, pre.x, shift, scale, gate)
+    assert cos(y.float().cpu()[rows], torch.from_numpy(rec["stage_self_attn_y"])) >= 0.9995
+    x, attn_out = inf.infer_cross_attn(ca, pre.x, pre.context, y, gate)
+    assert cos(attn_out.float().cpu()[rows], torch.from_numpy(rec["stage_cross_attn_y"])) >= 0.9995
+    yf = inf.infer_ffn(ff, x, attn_out, c_shift, c_scale, c_gate)
+    assert cos(yf.float().cpu()[rows], torch.from_numpy(rec["stage_ffn_y"])) >= 0.9995
+
+
+def test_two_blocks_stack_and_full_infer(cuda):
+    """infer(): blocks loop + head, two different blocks, against the oracle run end to end."""
+    rec = load_golden("tiny_d256_g3x6x8")
+    c = case_inputs(rec)
+    w2 = R.make_block_weights(c["dim"], c["ffn"], seed=int(rec["seed"]), block_index=1)
+    c["w"].update(w2)
+    W, inf = _build(c, cuda, n_layers=2)
+
+    class Sch:
+        cos_sin = inf.cos_sin
+
+    inf.set_scheduler(Sch())
+    pre = _pre(c, cuda)
+    out = inf.infer(W, pre)
+    x = c["x"]
+    for i in range(2):
+        x = R.block_forward(x, c["embed0"], c["context"], c["w"], c["cos_sin"], c["heads"], block_index=i)
+    ref = R.head_forward(x, c["embed"], c["hw"])
+    assert cos(out, ref) >= 0.9995

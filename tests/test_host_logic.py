@@ -1,0 +1,161 @@
+"""Host-side behaviour that needs no GPU: registry contract, module tree, RoPE table, the C ABI's
+exported symbols, and loud failure (never a fallback) when an op is handed a CPU tensor."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import lightx2v_amd as L
+from lightx2v_amd import hip, plugins, registry_factory, rope_table, wan_block
+from oracle import wan_block_ref as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_registry_contract():
+    reg = registry_factory.Register()
+
+    @reg("a")
+    class A:
+        pass
+
+    @reg
+    class B:
+        pass
+
+    assert reg["a"] is A and reg["B"] is B and "a" in reg and "zzz" not in reg
+    with pytest.raises(Exception, match="already exists"):
+        reg.register(A, key="a")
+    with pytest.raises(KeyError):
+        reg["missing"]
+    with pytest.raises(Exception, match="must be callable"):
+        reg.register(3, key="x")
+    assert set(reg.keys()) == {"a", "B"}
+
+
+def test_plugins_registered_under_reference_registry_names():
+    assert "hip_flash_attn" in L.ATTN_WEIGHT_REGISTER and "hip_ulysses" in L.ATTN_WEIGHT_REGISTER
+    assert "hip-bf16" in L.MM_WEIGHT_REGISTER and "hip" in L.LN_WEIGHT_REGISTER and "hip" in L.RMS_WEIGHT_REGISTER
+    assert "Default" in L.TENSOR_REGISTER
+
+
+def test_adopt_into_foreign_registries():
+    class Foreign:
+        MM_WEIGHT_REGISTER = registry_factory.Register()
+        ATTN_WEIGHT_REGISTER = registry_factory.Register()
+
+    added = registry_factory.adopt_into(Foreign)
+    assert "hip-bf16" in Foreign.MM_WEIGHT_REGISTER and "hip_flash_attn" in Foreign.ATTN_WEIGHT_REGISTER
+    assert added["ATTN_WEIGHT_REGISTER"] == ["hip_flash_attn", "hip_ulysses"]
+    assert registry_factory.adopt_into(Foreign) == {}  # idempotent
+
+
+def test_c_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "lx2v_hip.h")).read()
+    declared = set(re.findall(r"\b(lx2v_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(hip.EXPORTS), declared ^ set(hip.EXPORTS)
+    lib = ctypes.CDLL(hip.lib_path())
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert hip.load().lx2v_abi_version() == 1
+
+
+def test_ops_refuse_cpu_tensors_loudly():
+    x = torch.zeros(4, 64, dtype=torch.bfloat16)
+    with pytest.raises(hip.Lx2vError, match="GPU tensor"):
+        hip.ln_modulate(x)
+    with pytest.raises(hip.Lx2vError, match="GPU tensor"):
+        hip.gemm(x, x)
+    with pytest.raises(hip.Lx2vError):
+        L.ATTN_WEIGHT_REGISTER["hip_flash_attn"]().apply(torch.zeros(4, 1, 128, dtype=torch.bfloat16), torch.zeros(4, 1, 128, dtype=torch.bfloat16), torch.zeros(4, 1, 128, dtype=torch.bfloat16))
+
+
+def test_c_abi_argument_validation_without_launching():
+    lib = hip.load()
+    # null pointers / bad shapes are rejected before any HIP call
+    assert lib.lx2v_gemm_bf16(None, 64, 0, 0, None, 64, None, None, 64, 8, 8, 64, 0, None, 0, None, None) == -1
+    assert b"null" in lib.lx2v_last_error()
+    buf = ctypes.create_string_buffer(4096 + 16)
+    p = (ctypes.addressof(buf) + 15) & ~15
+    assert lib.lx2v_gemm_bf16(p, 64, 0, 0, p, 64, None, p, 64, 8, 8, 63, 0, None, 0, None, None) == -2   # K % 64
+    assert lib.lx2v_attn_fwd_bf16(p, 128, p, 128, p, 128, p, 128, 8, 8, 1, 64, 0.1, None, None) == -2      # head_dim != 128
+    assert lib.lx2v_ln_modulate_bf16(p, 64, p, None, None, None, p, 64, 4, 64, 1e-6, None) == -1          # ln_w without ln_b
+    assert lib.lx2v_ln_modulate_bf16(p + 2, 64, None, None, None, None, p, 64, 4, 64, 1e-6, None) == -1   # misaligned
+    assert lib.lx2v_rmsnorm_rope_bf16(p, 64, None, 1, None, 128, p, 64, 4, 9000, 1e-6, None) == -2        # dim too large / not multiple of 8
+    assert lib.lx2v_ulysses_pack_qkv_bf16(p, 64, p, 64, p, 64, p, 4, 64, 3, None) == -1                  # dim % (8*world)
+    # zero rows is a no-op success
+    assert lib.lx2v_ln_modulate_bf16(p, 64, None, None, None, None, p, 64, 0, 64, 1e-6, None) == 0
+
+
+@pytest.mark.parametrize("grid", [(2, 4, 4), (3, 6, 8), (21, 30, 52)])
+def test_rope_table_matches_oracle(grid):
+    mine = rope_table.build_rope_table(grid, 128)
+    ref = R.cos_sin_to_real(R.build_cos_sin(grid, 128))
+    assert mine.shape == ref.shape == (grid[0] * grid[1] * grid[2], 128)
+    assert (mine - ref).abs().max().item() < 2e-6
+    assert rope_table.axis_slots(128) == (22, 21, 21)
+
+
+def test_rope_table_sharding_pads_with_zeros():
+    t = rope_table.build_rope_table((1, 3, 3), 128)  # 9 tokens
+    parts = [rope_table.shard_rope_table(t, 4, r) for r in range(4)]
+    assert all(p.shape == (3, 128) for p in parts)
+    full = torch.cat(parts)
+    assert torch.equal(full[:9], t) and torch.count_nonzero(full[9:]) == 0
+    ref = torch.cat([R.cos_sin_to_real(R.pad_and_shard_cos_sin(R.build_cos_sin((1, 3, 3), 128), 4, r)) for r in range(4)])
+    assert (full - ref).abs().max().item() < 2e-6
+
+
+def _cfg(**kw):
+    c = {"num_layers": 2, "num_heads": 2, "dim": 256, "task": "t2v"}
+    c.update(kw)
+    return wan_block.with_defaults(c)
+
+
+def test_weight_tree_names_and_load_roundtrip():
+    cfg = _cfg()
+    W = L.WanTransformerWeights(cfg)
+    wd = {}
+    for i in range(2):
+        wd.update(R.make_block_weights(256, 512, seed=7, block_index=i))
+    wd.update(R.make_head_weights(256, 64, seed=7))
+    expected_keys = set(wd)
+    W.load(dict(wd))
+    sd = W.state_dict()
+    assert set(sd) == expected_keys
+    sa, ca, ff = W.blocks[1].compute_phases
+    assert sa.self_attn_q.weight_nk.dtype == torch.bfloat16 and sa.self_attn_q.weight_nk.shape == (256, 256)
+    assert sa.self_attn_q.weight.shape == (256, 256) and sa.self_attn_q.bias.dtype == torch.float32
+    assert ff.ffn_0.weight_nk.shape == (512, 256) and ff.ffn_2.weight_nk.shape == (256, 512)
+    assert ca.norm3.weight is not None and sa.norm1.weight is None and ff.norm2.weight is None
+    assert torch.equal(sd["blocks.1.self_attn.q.weight"].float(), wd["blocks.1.self_attn.q.weight"].to(torch.bfloat16).float())
+    names = [n for n, _ in W.named_parameters()]
+    assert "blocks.0.compute_phases.0.self_attn_q" in names and "head_modulation" in names
+    assert W.calculate_size() > 0
+    # fused q|k|v aliases the same storage as the per-projection plugins afterwards
+    w, b = sa.fused_qkv()
+    assert w.shape == (768, 256) and sa.self_attn_k.weight_nk.data_ptr() == w[256:512].data_ptr()
+    assert torch.equal(sa.self_attn_v.bias, b[512:])
+
+
+def test_unknown_plugin_names_fail():
+    with pytest.raises(KeyError):
+        L.WanTransformerWeights(_cfg(dit_quant_scheme="nope"))
+    with pytest.raises(KeyError):
+        L.WanTransformerWeights(_cfg(self_attn_1_type="flash_attn9"))
+    with pytest.raises(ValueError):
+        L.WanTransformerInfer(_cfg(rope_type="flashinfer"))
+
+
+def test_pre_process_chunk_order():
+    inf = L.WanTransformerInfer(_cfg())
+    mod = plugins.DefaultTensor("blocks.0.modulation")
+    mod.tensor = torch.arange(6 * 256, dtype=torch.float32).view(1, 6, 256)
+    e0 = torch.ones(6, 256)
+    parts = inf.pre_process(mod, e0)
+    ref = (mod.tensor + e0).chunk(6, dim=1)
+    assert len(parts) == 6
+    for a, b in zip(parts, ref):
+        assert torch.equal(a, b.reshape(-1))

@@ -1,0 +1,222 @@
+"""Each HIP kernel (through the C ABI) against the CPU oracle's op on the same seeded inputs.
+Inputs are rounded to bf16 first, so the only differences are the kernel's own arithmetic and the
+single bf16 rounding of its output.  Tolerances are stated per test."""
+import math
+
+import pytest
+import torch
+
+from lightx2v_amd import hip
+from oracle import wan_block_ref as R
+from tests.util import cos, rel_err
+
+pytestmark = pytest.mark.gpu
+
+BF16_EPS = 2.0 ** -8  # one bf16 rounding: relative error <= 2^-9, allow 2x
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (scale * torch.randn(*shape, generator=g)).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("rows,dim", [(1, 64), (7, 256), (130, 1536), (33, 5120), (5, 8192), (9, 520)])
+@pytest.mark.parametrize("affine,mod", [(False, True), (True, False), (True, True), (False, False)])
+def test_ln_modulate(cuda, rows, dim, affine, mod):
+    x = _rand((rows, dim), 1, 2.0) + 0.5
+    g = torch.Generator().manual_seed(2)
+    w = 1 + 0.1 * torch.randn(dim, generator=g) if affine else None
+    b = 0.1 * torch.randn(dim, generator=g) if affine else None
+    sc = 0.2 * torch.randn(dim, generator=g) if mod else None
+    sh = 0.2 * torch.randn(dim, generator=g) if mod else None
+    ref = R.layer_norm(x.float(), w, b)
+    if mod:
+        ref = R.modulate(ref, sc, sh)
+    out = hip.ln_modulate(x.to(cuda), w, b, sc, sh)
+    assert out.dtype == torch.bfloat16 and out.shape == (rows, dim)
+    assert (out.float().cpu() - ref).abs().max().item() <= BF16_EPS * ref.abs().max().item() + 1e-3
+
+
+@pytest.mark.parametrize("rows,dim,hd", [(3, 256, 128), (130, 1536, 128), (19, 5120, 128), (4, 512, 64)])
+@pytest.mark.parametrize("rope", [False, True])
+def test_rmsnorm_rope(cuda, rows, dim, hd, rope):
+    x = _rand((rows, dim), 3, 1.5)
+    g = torch.Generator().manual_seed(4)
+    w = 1 + 0.1 * torch.randn(dim, generator=g)
+    ref = R.rms_norm(x.float(), w)
+    table = None
+    if rope:
+        # a table with all three axes active
+        cs = R.build_cos_sin((rows, 2, 2), hd)[3::4][:rows]
+        ref, _ = R.rope_apply(ref.view(rows, dim // hd, hd), ref.view(rows, dim // hd, hd), cs)
+        ref = ref.reshape(rows, dim)
+        table = R.cos_sin_to_real(cs).contiguous().to(cuda)
+    out = hip.rmsnorm_rope(x.to(cuda), w, table, head_dim=hd)
+    assert (out.float().cpu() - ref).abs().max().item() <= BF16_EPS * ref.abs().max().item() + 1e-3
+    # in-place on a strided view (the q part of a fused q|k|v buffer)
+    big = torch.zeros(rows, 3 * dim, dtype=torch.bfloat16, device=cuda)
+    big[:, dim:2 * dim] = x.to(cuda)
+    view = big[:, dim:2 * dim]
+    hip.rmsnorm_rope(view, w, table, head_dim=hd, out=view)
+    assert torch.equal(view, out) and torch.count_nonzero(big[:, :dim]) == 0 and torch.count_nonzero(big[:, 2 * dim:]) == 0
+
+
+def test_rope_only_matches_oracle(cuda):
+    S, H, d = 96, 3, 128
+    q = _rand((S, H * d), 5)
+    cs = R.build_cos_sin((4, 4, 6), d)
+    ref, _ = R.rope_apply(q.float().view(S, H, d), q.float().view(S, H, d), cs)
+    out = hip.rmsnorm_rope(q.to(cuda), None, R.cos_sin_to_real(cs).to(cuda), head_dim=d, do_norm=False)
+    assert (out.float().cpu() - ref.reshape(S, -1)).abs().max().item() <= BF16_EPS * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("gated", [True, False])
+def test_gate_residual_and_gelu(cuda, gated):
+    x, y = _rand((37, 1536), 6), _rand((37, 1536), 7)
+    gate = 0.3 * torch.randn(1536, generator=torch.Generator().manual_seed(8)) if gated else None
+    ref = x.float() + (y.float() * gate if gated else y.float())
+    xd = x.to(cuda)
+    out = hip.gate_residual_(xd, y.to(cuda), gate)
+    assert out.data_ptr() == xd.data_ptr()
+    assert (out.float().cpu() - ref).abs().max().item() <= BF16_EPS * ref.abs().max().item()
+    h = _rand((64, 8960), 9, 2.0)
+    gref = torch.nn.functional.gelu(h.float(), approximate="tanh")
+    gout = hip.gelu_tanh(h.to(cuda))
+    assert (gout.float().cpu() - gref).abs().max().item() <= BF16_EPS * gref.abs().max().item() + 1e-3
+
+
+GEMM_SHAPES = [
+    (256, 256, 64), (1, 256, 64), (300, 512, 128), (257, 264, 192), (1000, 1536, 1536), (520, 64, 1536),
+    (512, 3072, 5120), (777, 8960, 1536), (333, 1536, 8960),
+]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_bias(cuda, M, N, K):
+    a, w = _rand((M, K), 10), _rand((N, K), 11, 0.05)
+    b = 0.1 * torch.randn(N, generator=torch.Generator().manual_seed(12))
+    ref = R.linear(a.float(), w.float(), b)
+    out = hip.gemm(a.to(cuda), w.to(cuda), b)
+    # fp32 accumulation of exact bf16 products in a different order than the CPU: ~sqrt(K) * 2^-24
+    # relative, far below the output's own bf16 rounding
+    assert (out.float().cpu() - ref).abs().max().item() <= BF16_EPS * ref.abs().max().item() + 1e-3
+    out2 = hip.gemm(a.to(cuda), w.to(cuda), None)
+    assert (out2.float().cpu() - R.linear(a.float(), w.float(), None)).abs().max().item() <= BF16_EPS * ref.abs().max().item() + 1e-3
+
+
+def test_gemm_mfma_operand_orientation_identity(cuda):
+    """A = I against an ASYMMETRIC W catches a transposed accumulator write-back."""
+    n = 256
+    a = torch.eye(n, dtype=torch.bfloat16)
+    w = (torch.arange(n * n, dtype=torch.float32).view(n, n) % 251 - 125).to(torch.bfloat16)  # exactly representable
+    out = hip.gemm(a.to(cuda), w.to(cuda), None)
+    assert torch.equal(out.float().cpu(), w.float().t())
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 512, 128), (1000, 1536, 1536)])
+def test_gemm_epilogues(cuda, M, N, K):
+    a, w = _rand((M, K), 13), _rand((N, K), 14, 0.05)
+    g = torch.Generator().manual_seed(15)
+    b = 0.1 * torch.randn(N, generator=g)
+    gate = 0.5 * torch.randn(N, generator=g)
+    resid = _rand((M, N), 16)
+    lin = R.linear(a.float(), w.float(), b)
+    gout = hip.gemm(a.to(cuda), w.to(cuda), b, epilogue=hip.EPI_GELU_TANH)
+    gref = torch.nn.functional.gelu(lin, approximate="tanh")
+    assert (gout.float().cpu() - gref).abs().max().item() <= BF16_EPS * gref.abs().max().item() + 1e-3
+    for gt in (gate, None):
+        r = resid.to(cuda).clone()
+        out = hip.gemm(a.to(cuda), w.to(cuda), b, epilogue=hip.EPI_RESIDUAL, resid=r, gate=gt, out=r)
+        assert out.data_ptr() == r.data_ptr()
+        ref = resid.float() + (lin * gt if gt is not None else lin)
+        # the product term is rounded to bf16 once before the add, then the sum once more
+        assert (out.float().cpu() - ref).abs().max().item() <= 2 * BF16_EPS * ref.abs().max().item() + 1e-3
+
+
+def test_gemm_k_segmented_operand(cuda):
+    """A given as [segments][M][kseg] (the Ulysses receive layout) equals the gathered matrix."""
+    M, N, kseg, nseg = 130, 256, 128, 4
+    segs = _rand((nseg, M, kseg), 17)
+    w = _rand((N, kseg * nseg), 18, 0.05)
+    a_full = segs.permute(1, 0, 2).reshape(M, nseg * kseg)
+    ref = R.linear(a_full.float(), w.float(), None)
+    sd = segs.to(cuda)
+    out = hip.gemm(sd.view(nseg * M, kseg)[:M], w.to(cuda), None, a_kseg=kseg, a_kseg_stride=M * kseg)
+    assert (out.float().cpu() - ref).abs().max().item() <= BF16_EPS * ref.abs().max().item() + 1e-3
+
+
+ATTN_SHAPES = [(64, 64, 1), (256, 64, 2), (100, 100, 1), (300, 520, 2), (257, 1, 1), (1, 257, 1), (1040, 1040, 3), (2000, 512, 2)]
+
+
+@pytest.mark.parametrize("sq,skv,H", ATTN_SHAPES)
+def test_attention_matches_sdpa(cuda, sq, skv, H):
+    q, k, v = _rand((sq, H, 128), 20), _rand((skv, H, 128), 21), _rand((skv, H, 128), 22)
+    ref = R.sdpa(q.float(), k.float(), v.float())
+    out = hip.attn_fwd(q.to(cuda), k.to(cuda), v.to(cuda))
+    assert out.shape == (sq, H * 128)
+    # P is rounded to bf16 before the PV product (relative 2^-9 per term, averaged by the sum) and
+    # the output once more; cosine is the north-star metric, the abs bound catches layout bugs.
+    assert cos(out, ref) >= 0.9999
+    assert (out.float().cpu() - ref).abs().max().item() <= 2e-2 * max(ref.abs().max().item(), 1.0)
+
+
+def test_attention_operand_layout_exact_integers(cuda):
+    """One-hot softmax (a single huge score per row) turns attention into a row gather of V with
+    asymmetric integer data: any key/dim permutation mistake in the MFMA operand maps shows up."""
+    S, H = 192, 2
+    q = torch.zeros(S, H, 128)
+    k = torch.zeros(S, H, 128)
+    perm = torch.randperm(S, generator=torch.Generator().manual_seed(3))
+    for i in range(S):
+        q[i, :, i % 128] = 16.0
+        q[i, :, (i // 128) + 64] = 16.0 if i >= 128 else 0.0
+    # key j matches query i iff j == perm[i]
+    k[perm] = q * 16.0
+    v = (torch.arange(S * H * 128, dtype=torch.float32).view(S, H, 128) % 199 - 99)
+    ref = R.sdpa(q, k, v)
+    out = hip.attn_fwd(q.to(torch.bfloat16).to(cuda), k.to(torch.bfloat16).to(cuda), v.to(torch.bfloat16).to(cuda))
+    assert (out.float().cpu() - ref).abs().max().item() <= 0.51  # bf16 rounding of |v| <= 99
+
+
+def test_attention_online_softmax_rescale_branch(cuda):
+    """Spike one key per query block late in the sequence so the running maximum jumps at a chosen
+    tile (forces the rescale path after many no-rescale tiles)."""
+    S, H = 640, 1
+    q, k, v = _rand((S, H, 128), 30, 0.3), _rand((S, H, 128), 31, 0.3), _rand((S, H, 128), 32)
+    k = k.float()
+    k[500] = q[5].float() * 40.0    # huge score for row 5 at tile 7
+    k[70] = q[300].float() * 25.0   # and for row 300 at tile 1
+    k = k.to(torch.bfloat16)
+    ref = R.sdpa_naive(q.float(), k.float(), v.float())
+    out = hip.attn_fwd(q.to(cuda), k.to(cuda), v.to(cuda))
+    assert (out.double().cpu() - ref).abs().max().item() <= 2e-2 * max(ref.abs().max().item(), 1.0)
+    assert cos(out, ref.float()) >= 0.9999
+
+
+def test_attention_strided_inputs_and_fused_rope(cuda):
+    S, H, d = 360, 2, 128
+    qkv = _rand((S, 3 * H * d), 40)
+    cs = R.build_cos_sin((3, 10, 12), d)
+    q, k, v = (qkv[:, i * H * d:(i + 1) * H * d].float().view(S, H, d) for i in range(3))
+    qr, kr = R.rope_apply(q, k, cs)
+    ref = R.sdpa(qr, kr, v)
+    dev = qkv.to(cuda)
+    views = [dev[:, i * H * d:(i + 1) * H * d].unflatten(1, (H, d)) for i in range(3)]
+    out = hip.attn_fwd(*views, rope_cos_sin=R.cos_sin_to_real(cs).to(cuda))
+    assert cos(out, ref) >= 0.9999
+    assert (out.float().cpu() - ref).abs().max().item() <= 2e-2
+    # pre-rotated path agrees with the fused one up to the extra bf16 rounding of rotated q/k
+    table = R.cos_sin_to_real(cs).to(cuda)
+    q2 = hip.rmsnorm_rope(dev[:, :H * d], None, table, head_dim=d, do_norm=False)
+    k2 = hip.rmsnorm_rope(dev[:, H * d:2 * H * d], None, table, head_dim=d, do_norm=False)
+    out2 = hip.attn_fwd(q2.view(S, H, d), k2.view(S, H, d), views[2])
+    assert cos(out2, ref) >= 0.9999
+
+
+def test_ulysses_pack_layout(cuda):
+    rows, dim, world = 24, 512, 4
+    q, k, v = _rand((rows, dim), 50), _rand((rows, dim), 51), _rand((rows, dim), 52)
+    out = hip.ulysses_pack_qkv(q.to(cuda), k.to(cuda), v.to(cuda), world).cpu()
+    seg = dim // world
+    exp = torch.stack([q, k, v], dim=1).view(rows, 3, world, seg).permute(2, 0, 1, 3)
+    assert torch.equal(out, exp)

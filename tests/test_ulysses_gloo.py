@@ -1,0 +1,84 @@
+"""The N>1 exchange logic on CPU: world_size 2 (and 4) gloo processes drive HipUlyssesAttnWeight with
+host tensors.  The pack step and the attention module are test doubles (a torch permutation and the
+oracle's SDPA) injected through the plugin's constructor/arguments, so what is checked here is the
+product's all-to-all layout, group construction and CFG gather -- not a compute fallback."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import wan_block_ref as R
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _torch_pack(q, k, v, world):
+    rows, dim = q.shape
+    seg = dim // world
+    st = torch.stack([q, k, v], dim=1).view(rows, 3, world, seg)
+    return st.permute(2, 0, 1, 3).contiguous()
+
+
+class _OracleAttn:
+    def apply(self, q, k, v, **kw):
+        return R.sdpa(q.float(), k.float(), v.float()).to(q.dtype)
+
+
+def _worker(rank, world, port, cfg_p, seq_p, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lightx2v_amd import ulysses
+
+    cfg_idx, seq_idx, seq_group, cfg_group = ulysses.make_groups(cfg_p, seq_p)
+    assert rank == cfg_idx * seq_p + seq_idx
+    S, H, d = 8 * seq_p, 2 * seq_p, 128
+    g = torch.Generator().manual_seed(100 + cfg_idx)  # cond / uncond branches see different data
+    q, k, v = (torch.randn(S, H, d, generator=g) for _ in range(3))
+    ql, kl, vl = (t.chunk(seq_p)[seq_idx].contiguous() for t in (q, k, v))
+    Sl = S // seq_p
+    uly = ulysses.HipUlyssesAttnWeight(pack_fn=_torch_pack)
+    out = uly.apply(ql, kl, vl, img_qkv_len=Sl, cu_seqlens_qkv=torch.tensor([0, Sl], dtype=torch.int32),
+                    attention_module=_OracleAttn(), seq_p_group=seq_group)
+    ref = R.sdpa(q, k, v).chunk(seq_p)[seq_idx]
+    err = (out - ref).abs().max().item()
+    # zero-copy form: logical matrix [Sl, H*d] described by K segments
+    buf, kseg, kstride = uly.apply_segmented(ql, kl, vl, attention_module=_OracleAttn(), seq_p_group=seq_group)
+    flat = buf.reshape(-1) if buf.is_contiguous() else None
+    base = buf.storage_offset()
+    storage = torch.as_strided(buf, (seq_p * Sl * kseg,), (1,), base)
+    logical = torch.stack([storage[s * kstride:(s * kstride + Sl * kseg)].view(Sl, kseg) for s in range(seq_p)], dim=1).reshape(Sl, seq_p * kseg)
+    err2 = (logical - ref).abs().max().item()
+    # H not divisible by N must raise, not floor silently
+    raised = False
+    try:
+        uly.apply(ql[:, :H - 1], kl[:, :H - 1], vl[:, :H - 1], img_qkv_len=Sl, cu_seqlens_qkv=torch.tensor([0, Sl]), attention_module=_OracleAttn(), seq_p_group=seq_group)
+    except ValueError:
+        raised = True
+    ok_cfg = True
+    if cfg_p == 2:
+        local = torch.full((4, 3), float(cfg_idx + 1))  # cond rank holds 1s, uncond rank 2s
+        comb = ulysses.cfg_parallel_combine(local, cfg_group, 5.0)
+        ok_cfg = torch.allclose(comb, torch.full((4, 3), 2.0 + 5.0 * (1.0 - 2.0)))
+    torch.save({"err": err, "err2": err2, "raised": raised or seq_p == 1, "ok_cfg": ok_cfg}, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cfg_p,seq_p", [(1, 2), (2, 2), (1, 4)])
+def test_ulysses_and_cfg_groups_gloo(tmp_path, cfg_p, seq_p):
+    world = cfg_p * seq_p
+    mp.spawn(_worker, args=(world, _free_port(), cfg_p, seq_p, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        res = torch.load(os.path.join(str(tmp_path), f"r{r}.pt"))
+        assert res["err"] < 1e-5 and res["err2"] < 1e-5, res
+        assert res["raised"] and res["ok_cfg"], res
