@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""Seconds per denoising step of the Wan DiT hot path on MI355X (synthetic data, random-init weights).
+
+One "step" = one `WanModel.infer`-equivalent pass: a conditional and an unconditional DiT forward
+(every transformer block + the head) and the classifier-free-guidance combine.  At N=1 both
+forwards run back to back on the one GPU; at N>1 the ranks form a (cfg_p, seq_p) grid like the
+reference's device mesh: cfg_p=2 puts the two forwards on two rank groups (one all_gather of the
+prediction), seq_p>1 shards tokens Ulysses-style (one fused q|k|v all-to-all + one return
+all-to-all per block, one final all_gather).  Total work is fixed as N grows (strong scaling).
+
+    python bench.py --gpus 1 --steps 2 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 2 --warmup 1
+
+Rank 0 prints ONE JSON line (metric s/denoise-step; roofline of the self-attention kernel measured
+live with events on the launch stream; at N=1 a CPU baseline from the fp32 oracle on a bounded
+sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+MODELS = {
+    # name: dim, heads, ffn, layers
+    "wan2.1-t2v-14b": (5120, 40, 13824, 40),
+    "wan2.1-t2v-1.3b": (1536, 12, 8960, 30),
+}
+GRIDS = {"720p": (21, 45, 80), "480p": (21, 30, 52)}  # (f, h, w) latent tokens for 81 frames, patch (1,2,2)
+TEXT_LEN = 512
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X
+GUIDE_SCALE = 5.0
+
+
+def block_flops(S, D, H, F, T=TEXT_LEN):
+    d = D // H
+    self_attn = 4.0 * S * S * H * d
+    cross = 4.0 * S * T * D
+    gemm = 8.0 * S * D * D + 4.0 * S * D * D + 4.0 * T * D * D + 4.0 * S * D * F
+    return self_attn, cross, gemm
+
+
+def default_layout(n):
+    return {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (2, 4)}.get(n, (1, n))
+
+
+def build_model(cfg, device, seed):
+    """Random-init weights of the named architecture, generated on the GPU block by block."""
+    import lightx2v_amd as L
+
+    D, F = cfg["dim"], cfg["ffn_dim"]
+    W = L.WanTransformerWeights(cfg)
+    g = torch.Generator(device=device).manual_seed(seed)
+
+    def rn(*shape, std=1.0, dtype=torch.bfloat16):
+        return (torch.randn(*shape, generator=g, device=device, dtype=torch.float32) * std).to(dtype)
+
+    for i in range(cfg["num_layers"]):
+        p = f"blocks.{i}."
+        wd = {}
+        for name in ("self_attn.q", "self_attn.k", "self_attn.v", "self_attn.o", "cross_attn.q", "cross_attn.k", "cross_attn.v", "cross_attn.o", "ffn.0", "ffn.2"):
+            out_f = F if name == "ffn.0" else D
+            in_f = F if name == "ffn.2" else D
+            wd[p + name + ".weight"] = rn(out_f, in_f, std=0.02)
+            wd[p + name + ".bias"] = rn(out_f, std=0.02, dtype=torch.float32)
+        for name in ("self_attn.norm_q", "self_attn.norm_k", "cross_attn.norm_q", "cross_attn.norm_k"):
+            wd[p + name + ".weight"] = torch.ones(D, device=device)
+        wd[p + "norm3.weight"] = torch.ones(D, device=device)
+        wd[p + "norm3.bias"] = torch.zeros(D, device=device)
+        wd[p + "modulation"] = rn(1, 6, D, std=1.0 / math.sqrt(D), dtype=torch.float32)
+        W.blocks[i].load(wd)
+        sa, ca, _ = W.blocks[i].compute_phases
+        sa.fused_qkv()
+        ca.fused_kv()
+    hw = {"head.head.weight": rn(64, D, std=0.02), "head.head.bias": rn(64, std=0.02, dtype=torch.float32),
+          "head.modulation": rn(1, 2, D, std=1.0 / math.sqrt(D), dtype=torch.float32)}
+    W.head.load(hw)
+    W.head_modulation.load(hw)
+    return W
+
+
+class AttnTimer:
+    """Wraps the self-attention plugin's apply with events recorded on the stream it launches on."""
+
+    def __init__(self, plugin):
+        self.plugin = plugin
+        self.inner = plugin.apply
+        self.events = []
+        self.enabled = False
+        plugin.apply = self.apply
+
+    def apply(self, *a, **kw):
+        if not self.enabled:
+            return self.inner(*a, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream())
+        out = self.inner(*a, **kw)
+        e1.record(torch.cuda.current_stream())
+        self.events.append((e0, e1))
+        return out
+
+    def mean_ms(self):
+        return sum(a.elapsed_time(b) for a, b in self.events) / max(1, len(self.events))
+
+
+def cpu_baseline(D, H, F, full_S, layers, threads):
+    """fp32 oracle block (torch_sdpa-equivalent) on the host cores, on a bounded sample: one block
+    of the same architecture at a reduced token count; extrapolated to the full step by FLOPs."""
+    from oracle import wan_block_ref as R
+
+    torch.set_num_threads(threads)
+    grid = (3, 45, 80) if full_S > 20000 else (2, 30, 52)
+    S = grid[0] * grid[1] * grid[2]
+    w = R.make_block_weights(D, F, seed=0)
+    x, context, embed0, _ = R.make_inputs(S, D, TEXT_LEN, seed=0)
+    cs = R.build_cos_sin(grid, D // H)
+    with torch.no_grad():
+        t0 = time.time()
+        R.block_forward(x, embed0, context, w, cs, H)
+        dt = time.time() - t0
+    sample_flops = sum(block_flops(S, D, H, F))
+    rate = sample_flops / dt  # FLOP/s on this host
+    full_flops = sum(block_flops(full_S, D, H, F)) * layers * 2
+    return {
+        "value": full_flops / rate, "unit": "s/denoise-step", "cores": threads, "kind": "port",
+        "sample": f"one fp32 oracle block at S={S} tokens ({grid[0]}x{grid[1]}x{grid[2]}), D={D}, took {dt:.1f} s = {rate / 1e12:.3f} TFLOP/s; "
+                  f"extrapolated by algorithmic FLOPs to {layers} blocks x 2 CFG passes at S={full_S}",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default=os.environ.get("LX2V_BENCH_MODEL", "wan2.1-t2v-14b"), choices=sorted(MODELS))
+    ap.add_argument("--res", default=os.environ.get("LX2V_BENCH_RES", "720p"), choices=sorted(GRIDS))
+    ap.add_argument("--layout", default=None, help="cfg_p x seq_p, e.g. 2x4 (default: 1x1, 2x1, 2x2, 2x4 for 1/2/4/8 GPUs)")
+    ap.add_argument("--layers", type=int, default=None, help="override the layer count (debug only; the JSON line then says so)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    cfg_p, seq_p = default_layout(world) if args.layout is None else tuple(int(v) for v in args.layout.lower().split("x"))
+    assert cfg_p * seq_p == world and cfg_p in (1, 2)
+
+    import lightx2v_amd as L
+    from lightx2v_amd import ulysses
+
+    D, H, F, layers = MODELS[args.model]
+    if args.layers is not None:
+        layers = args.layers
+    grid = GRIDS[args.res]
+    S = grid[0] * grid[1] * grid[2]
+    if H % seq_p != 0:
+        raise SystemExit(f"num_heads={H} not divisible by seq_p={seq_p}")
+
+    cfg_idx = seq_idx = 0
+    seq_group = cfg_group = None
+    if world > 1:
+        cfg_idx, seq_idx, seq_group, cfg_group = ulysses.make_groups(cfg_p, seq_p)
+    cfg = {"num_layers": layers, "num_heads": H, "dim": D, "ffn_dim": F, "task": "t2v", "model_cls": "wan2.1",
+           "seq_parallel": seq_p > 1, "seq_p_group": seq_group, "parallel": {"seq_p_size": seq_p, "cfg_p_size": cfg_p, "seq_p_attn_type": "hip_ulysses"}}
+    W = build_model(cfg, dev, seed=1234)  # same seed on every rank: weights are replicated
+    inf = L.WanTransformerInfer(cfg)
+
+    # synthetic step inputs (what pre_infer would hand over), token-sharded under seq_p
+    S_pad = S + (seq_p - S % seq_p) % seq_p
+    S_loc = S_pad // seq_p
+    table = L.shard_rope_table(L.build_rope_table(grid, D // H), seq_p, seq_idx).to(dev)
+    g = torch.Generator(device=dev).manual_seed(99)
+    x_full = torch.randn(S_pad, D, generator=g, device=dev, dtype=torch.float32)
+    x_full[S:] = 0
+    x0 = x_full[seq_idx * S_loc:(seq_idx + 1) * S_loc].to(torch.bfloat16).contiguous()
+    del x_full
+    contexts = [torch.randn(TEXT_LEN, D, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16) for _ in range(2)]  # cond, uncond
+    embed0 = 0.1 * torch.randn(6, D, generator=g, device=dev, dtype=torch.float32)
+    embed = 0.1 * torch.randn(1, D, generator=g, device=dev, dtype=torch.float32)
+
+    class Sch:
+        cos_sin = table
+
+    inf.set_scheduler(Sch())
+    timers = [AttnTimer(W.blocks[i].compute_phases[0].self_attn_1) for i in range(layers)]
+
+    def forward(which):
+        pre = L.WanPreInferModuleOutput(embed=embed, grid_sizes=grid, x=x0.clone(), embed0=embed0, context=contexts[which])
+        out = inf.infer(W, pre)  # [S_loc, 64]
+        if seq_p > 1:
+            parts = [torch.empty_like(out) for _ in range(seq_p)]
+            dist.all_gather(parts, out, group=seq_group)
+            out = torch.cat(parts, dim=0)[:S]
+        return out.float()
+
+    def step():
+        if cfg_p == 1:
+            cond, uncond = forward(0), forward(1)
+            return uncond + GUIDE_SCALE * (cond - uncond)
+        return ulysses.cfg_parallel_combine(forward(cfg_idx), cfg_group, GUIDE_SCALE)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    for t in timers:
+        t.enabled = True
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        noise_pred = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(noise_pred).all()
+    s_per_step = elapsed / args.steps
+
+    attn_ms = sum(t.mean_ms() for t in timers) / len(timers)
+    attn_flops = 4.0 * S_pad * S_pad * (H // seq_p) * (D // H)  # per launch on this rank
+    achieved = attn_flops / (attn_ms * 1e-3) / 1e12
+    sa, ca, ge = block_flops(S, D, H, F)
+    step_flops = (sa + ca + ge) * layers * 2
+
+    if rank == 0:
+        line = {
+            "metric": "s/denoise-step Wan2.1-T2V-14B 720p81f" if (args.model, args.res) == ("wan2.1-t2v-14b", "720p") else f"s/denoise-step {args.model} {args.res}81f",
+            "value": s_per_step, "unit": "s/denoise-step", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": s_per_step * 1e3, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic latents/text/timestep embeddings, random-init weights of the named architecture",
+            "config": {"workload": f"{args.model} {args.res} x81f: {S} tokens, {layers} blocks + head, 2 CFG forwards per step, text len {TEXT_LEN}",
+                       "parallelism": f"cfg_p{cfg_p} x seq_p{seq_p} (ulysses)", "tokens": S, "dim": D, "heads": H, "ffn_dim": F, "layers": layers},
+            "step_tflops": step_flops / 1e12,
+            "achieved_tflops_per_gpu": step_flops / s_per_step / 1e12 / world,
+            "roofline": {"kernel": "attn_fwd_kernel (self-attention)", "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                         "launch_ms": attn_ms, "flops_per_launch": attn_flops, "launches_timed": sum(len(t.events) for t in timers)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+            line["cpu_baseline"] = cpu_baseline(D, H, F, S, layers, threads)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
