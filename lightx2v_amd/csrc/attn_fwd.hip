@@ -74,7 +74,24 @@ LX2V_DEVICE float half_swap_sum(float x) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-template <bool ROPE>
+// Wave-uniform buffer descriptor over [base, base + bytes): loads past the end return 0, which is
+// how key rows >= skv of the last tile become zero rows without any per-lane clamping.
+LX2V_DEVICE __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  void* pb = reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(pb, 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
+template <int N>
+struct IntC {
+  static constexpr int value = N;
+};
+
+// SHORT_KV only gives the cross-attention launches (a few hundred keys) their own kernel symbol,
+// so per-kernel profiles separate them from the long self-attention launches.
+template <bool ROPE, bool SHORT_KV>
 __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) char lds[4 * KV_TILE_BYTES];  // [buf][K|V]
 
@@ -89,27 +106,31 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AttnParams p) 
 
   // ---- Q^T fragments: lane holds Q[q0 + r32][16 ks + 8 h .. +7] for ks = 0..7 ----
   bf16x8 qf[8];
+  u32x4 qraw[8];
+  const int qrow_c = min(q0 + r32, p.sq - 1);
   {
-    const int qrow = min(q0 + r32, p.sq - 1);
-    const uint16_t* qp = p.q + (int64_t)qrow * p.ldq + head * HD + h * 8;
+    const uint16_t* qp = p.q + (int64_t)qrow_c * p.ldq + head * HD + h * 8;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      u32x4 v = *reinterpret_cast<const u32x4*>(qp + ks * 16);
-      if (ROPE) v = rope_chunk(v, p.rope + (int64_t)qrow * HD, 8 * ks + 4 * h);
-      qf[ks] = __builtin_bit_cast(bf16x8, v);
-    }
+    for (int ks = 0; ks < 8; ++ks) qraw[ks] = *reinterpret_cast<const u32x4*>(qp + ks * 16);
   }
 
   // ---- K/V staging: thread owns chunks c = tid + 512 i (i = 0,1): row = c >> 4, ch = c & 15 ----
   const int srow0 = tid >> 4, sch = tid & 15;  // second chunk: row + 32
-  const uint16_t* kbase = p.k + head * HD + sch * 8;
-  const uint16_t* vbase = p.v + head * HD + sch * 8;
+  const __amdgpu_buffer_rsrc_t k_rs = make_rsrc(p.k + head * HD, (uint32_t)((int64_t)p.skv * p.ldk * 2));
+  const __amdgpu_buffer_rsrc_t v_rs = make_rsrc(p.v + head * HD, (uint32_t)((int64_t)p.skv * p.ldv * 2));
+  const __amdgpu_buffer_rsrc_t t_rs = make_rsrc(ROPE ? p.rope : nullptr, ROPE ? (uint32_t)((int64_t)p.skv * HD * 4) : 0u);
+  int k_vo[2], v_vo[2], t_vo[2];  // per-lane byte offsets inside a tile; the tile offset is scalar
   int k_wr[2], v_wr[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    k_wr[i] = k_lds_off(srow0 + 32 * i, sch);
-    v_wr[i] = KV_TILE_BYTES + v_lds_off(srow0 + 32 * i, sch);
+    const int row = srow0 + 32 * i;
+    k_vo[i] = (int)(row * p.ldk * 2) + sch * 16;
+    v_vo[i] = (int)(row * p.ldv * 2) + sch * 16;
+    t_vo[i] = row * (HD * 4) + sch * 16;
+    k_wr[i] = k_lds_off(row, sch);
+    v_wr[i] = KV_TILE_BYTES + v_lds_off(row, sch);
   }
+  const int k_tile_bytes = (int)(KVB * p.ldk * 2), v_tile_bytes = (int)(KVB * p.ldv * 2);
   u32x4 kreg[2], vreg[2];
   f32x4 rcos[2], rsin[2];  // only live when ROPE
   // Loads only: nothing here may consume the loaded registers, or the wait for them would land
@@ -117,22 +138,21 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AttnParams p) 
   auto load_tile = [&](int t) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int rc = min(t * KVB + srow0 + 32 * i, p.skv - 1);
-      kreg[i] = *reinterpret_cast<const u32x4*>(kbase + (int64_t)rc * p.ldk);
-      vreg[i] = *reinterpret_cast<const u32x4*>(vbase + (int64_t)rc * p.ldv);
+      kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rs, k_vo[i], t * k_tile_bytes, 0));
+      vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(v_rs, v_vo[i], t * v_tile_bytes, 0));
       if (ROPE) {
-        const float* cs = p.rope + (int64_t)rc * HD + 4 * sch;
-        rcos[i] = *reinterpret_cast<const f32x4*>(cs);
-        rsin[i] = *reinterpret_cast<const f32x4*>(cs + 64);
+        rcos[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(t_rs, t_vo[i], t * (KVB * HD * 4), 0));
+        rsin[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(t_rs, t_vo[i] + 256, t * (KVB * HD * 4), 0));
       }
     }
   };
-  // Rotate (ROPE), zero rows past skv, write to LDS buffer `buf`.
-  auto write_tile = [&](int buf, int t) {
-    char* base = lds + buf * 2 * KV_TILE_BYTES;
+  // Rotate (ROPE) and write to LDS buffer BUF.
+  auto write_tile = [&](auto bufc) {
+    constexpr int BUF = decltype(bufc)::value;
+    char* base = lds + BUF * 2 * KV_TILE_BYTES;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      u32x4 kv = kreg[i], vv = vreg[i];
+      u32x4 kv = kreg[i];
       if (ROPE) {
         float f[8];
         unpack8(kv, f);
@@ -144,21 +164,16 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AttnParams p) 
         }
         kv = pack8(f);
       }
-      if (t * KVB + srow0 + 32 * i >= p.skv) {
-        kv = u32x4{0u, 0u, 0u, 0u};
-        vv = u32x4{0u, 0u, 0u, 0u};
-      }
       *reinterpret_cast<u32x4*>(base + k_wr[i]) = kv;
-      *reinterpret_cast<u32x4*>(base + v_wr[i]) = vv;
+      *reinterpret_cast<u32x4*>(base + v_wr[i]) = vreg[i];
     }
   };
 
-  // ---- fragment read offsets ----
-  // K (A operand of S^T): row = kb*32 + r32, chunk = 2 ks + h
-  int k_rd[2];
+  // ---- fragment read offsets (per-lane VGPRs; buffer / key-block / d-block offsets are immediates) ----
+  // K (A operand of S^T): row = kb*32 + r32, chunk = 2 ks + h, swizzled by row & 15 == r32 & 15
+  int k_rd[8];
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb) k_rd[kb] = (kb * 32 + r32) * 256;  // + ((2ks+h) ^ (row&15)) << 4, row&15 == r32&15
-  const int k_sw = r32 & 15;
+  for (int ks = 0; ks < 8; ++ks) k_rd[ks] = r32 * 256 + (((2 * ks + h) ^ (r32 & 15)) << 4);
   // V^T (A operand of O^T): per 16-lane group g2 = (lane>>4)&1, lane-in-group li = lane & 15 -> q4 = li>>2, p4 = li&3
   //   block rows r0 = 32 kb + 16 s + 8 u + 4 h (u = 0,1 -> elements 0..3 / 4..7), cols 32 db + 16 g2 .. +15
   //   this lane supplies row r0 + q4, chunk c0 + (p4 >> 1) with c0 = 4 db + 2 g2, byte +8 (p4 & 1)
@@ -181,13 +196,12 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AttnParams p) 
   float m_run = -1e30f, l_run = 0.f;
 
   const int nt = (p.skv + KVB - 1) / KVB;
-  load_tile(0);
-  write_tile(0, 0);
-  if (nt > 1) load_tile(1);
-  __syncthreads();
+  const bool ragged = (p.skv & (KVB - 1)) != 0;
 
-  for (int t = 0; t < nt; ++t) {
-    const char* kb_base = lds + (t & 1) * 2 * KV_TILE_BYTES;
+  // One K/V tile against this wave's 32 query rows; BUF is the LDS buffer holding tile t.
+  auto tile = [&](auto bufc, int t) {
+    constexpr int BUF = decltype(bufc)::value;
+    const char* kb_base = lds + BUF * 2 * KV_TILE_BYTES;
 
     // ---- S^T = K Q^T ----
     f32x16 s[2];
@@ -199,19 +213,19 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AttnParams p) 
     for (int ks = 0; ks < 8; ++ks) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(kb_base + k_rd[kb] + (((2 * ks + h) ^ k_sw) << 4));
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(kb_base + kb * 8192 + k_rd[ks]);
         s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s[kb], 0, 0, 0);
       }
     }
 
     // ---- stage tile t+1 into the other buffer, issue the loads of tile t+2 ----
     if (t + 1 < nt) {
-      write_tile((t + 1) & 1, t + 1);
+      write_tile(IntC<BUF ^ 1>{});
       if (t + 2 < nt) load_tile(t + 2);
     }
 
     // ---- mask keys past skv (last tile only) ----
-    if (t == nt - 1 && (p.skv & (KVB - 1)) != 0) {
+    if (ragged && t == nt - 1) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -238,7 +252,8 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AttnParams p) 
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
     }
-    const float mc = m_run * p.c;
+    float neg_mc = -m_run * p.c;
+    asm volatile("" : "+v"(neg_mc));  // keep exp2(fma(s, c, -m c)) one FMA: no refactoring to (s - m) * c
     bf16x8 pf[4];
     float lsum = 0.f;
 #pragma unroll
@@ -248,7 +263,7 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AttnParams p) 
         bf16x8 f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float e = __builtin_amdgcn_exp2f(s[kb][8 * sidx + j] * p.c - mc);
+          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][8 * sidx + j], p.c, neg_mc));
           lsum += e;
           f[j] = (__bf16)e;
         }
@@ -268,7 +283,27 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AttnParams p) 
       }
     }
     __syncthreads();
+  };
+
+  // ---- prologue: K0/V0 -> LDS, K1/V1 in flight, Q fragments final before the loop ----
+  load_tile(0);
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    u32x4 v = qraw[ks];
+    if (ROPE) v = rope_chunk(v, p.rope + (int64_t)qrow_c * HD, 8 * ks + 4 * h);
+    asm volatile("" : "+v"(v));  // the wait for the Q loads lands here, not inside the tile loop
+    qf[ks] = __builtin_bit_cast(bf16x8, v);
   }
+  write_tile(IntC<0>{});
+  if (nt > 1) load_tile(1);
+  __syncthreads();
+
+  int t = 0;
+  for (; t + 1 < nt; t += 2) {
+    tile(IntC<0>{}, t);
+    tile(IntC<1>{}, t + 1);
+  }
+  if (t < nt) tile(IntC<0>{}, t);
 
   // ---- normalise and store: o[db][i] = O[q0 + r32][32 db + 8 (i>>2) + 4 h + (i&3)] ----
   const float inv = 1.0f / half_swap_sum(l_run);
@@ -314,10 +349,15 @@ extern "C" int lx2v_attn_fwd_bf16(const uint16_t* q, int64_t ldq, const uint16_t
   const int64_t nwg = (int64_t)p.nqb * heads;
   LX2V_REQUIRE(nwg < (1LL << 31), LX2V_EUNSUP, "attn_fwd: grid too large");
   const dim3 grid((unsigned)nwg), block(NTHREADS);
+  LX2V_REQUIRE(skv * ldk * 2 < (1LL << 32) && skv * ldv * 2 < (1LL << 32), LX2V_EUNSUP,
+               "attn_fwd: K/V extent (skv * token stride) must stay below 4 GiB for 32-bit buffer offsets");
+  hipStream_t st = (hipStream_t)stream;
   if (rope_cos_sin != nullptr)
-    hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid, block, 0, st, p);
+  else if (skv <= 2048)
+    hipLaunchKernelGGL((attn_fwd_kernel<false, true>), grid, block, 0, st, p);
   else
-    hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<false, false>), grid, block, 0, st, p);
   LX2V_CHECK_LAUNCH("attn_fwd");
   return LX2V_OK;
 }
