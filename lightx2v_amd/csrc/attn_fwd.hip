@@ -18,6 +18,8 @@
 //                    ds_read_b64_tr_b16 from a [8 keys][32 cols] sub-tiled V image in the k order
 //                    the accumulator layout dictates (key = 16s + 8(j>>2) + 4h + (j&3)).
 // Optional fused 3-axis RoPE: q and k are rotated (interleaved pairs, fp32) as they are loaded.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -89,9 +91,20 @@ struct IntC {
   static constexpr int value = N;
 };
 
+// Rescale threshold in log2 units: O and l are rescaled only on tiles where some row's running
+// maximum would grow by more than this, so P stays <= 2^kRescaleThr (bf16 keeps its relative
+// precision at any magnitude; O and l accumulate in fp32).
+constexpr float kRescaleThr = 6.0f;
+
 // SHORT_KV only gives the cross-attention launches (a few hundred keys) their own kernel symbol,
 // so per-kernel profiles separate them from the long self-attention launches.
-template <bool ROPE, bool SHORT_KV>
+//
+// VARIANT 0: plain order per tile: S^T, stage, softmax, PV, barrier.
+// VARIANT 1: same work with the LDS reads software-pipelined: the K fragments of the first
+// k-steps are requested right after the tile barrier, which sits BEFORE the last four PV MFMAs of
+// the previous tile, and the remaining K fragments are requested behind the MFMAs that free their
+// registers, so no S^T MFMA waits a full LDS round trip.
+template <bool ROPE, bool SHORT_KV, int VARIANT>
 __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) char lds[4 * KV_TILE_BYTES];  // [buf][K|V]
 
@@ -104,7 +117,7 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AttnParams p) 
   const int head = blockIdx.x / p.nqb;
   const int q0 = qb * QROWS + wid * 32;
 
-  // ---- Q^T fragments: lane holds Q[q0 + r32][16 ks + 8 h .. +7] for ks = 0..7 ----
+  // ---- Q^T fragments: lane holds c * Q[q0 + r32][16 ks + 8 h .. +7] for ks = 0..7 ----
   bf16x8 qf[8];
   u32x4 qraw[8];
   const int qrow_c = min(q0 + r32, p.sq - 1);
@@ -193,39 +206,65 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AttnParams p) 
   for (int db = 0; db < 4; ++db)
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
+  // Running maximum m of this lane's query row (log2 domain, scores already scaled through Q).
+  // negm holds -m in all 16 registers: it is the C operand of the first S^T MFMA of every tile, so
+  // the accumulators come out as s - m and exp2 needs no per-element subtract.
+  f32x16 negm;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) negm[i] = 0.f;
+  float l_run = 0.f;
 
   const int nt = (p.skv + KVB - 1) / KVB;
   const bool ragged = (p.skv & (KVB - 1)) != 0;
 
-  // One K/V tile against this wave's 32 query rows; BUF is the LDS buffer holding tile t.
-  auto tile = [&](auto bufc, int t) {
+  // ---- S^T - m = K (cQ)^T - m for the tile in LDS buffer BUF ----
+  auto qk = [&](auto bufc, f32x16 (&s)[2]) {
     constexpr int BUF = decltype(bufc)::value;
     const char* kb_base = lds + BUF * 2 * KV_TILE_BYTES;
-
-    // ---- S^T = K Q^T ----
-    f32x16 s[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         const bf16x8 a = *reinterpret_cast<const bf16x8*>(kb_base + kb * 8192 + k_rd[ks]);
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s[kb], 0, 0, 0);
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], ks == 0 ? negm : s[kb], 0, 0, 0);
       }
     }
+  };
+  constexpr int KPF = 2;  // VARIANT 1: k-steps of K fragments kept in flight ahead of their MFMAs
+  bf16x8 ka[2 * KPF];     // [2 (ks % KPF) + kb]
+  auto k_prefetch = [&](auto bufc) {  // k-steps 0..KPF-1 of the tile in buffer BUF
+    constexpr int BUF = decltype(bufc)::value;
+    const char* kb_base = lds + BUF * 2 * KV_TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < KPF; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) ka[2 * ks + kb] = *reinterpret_cast<const bf16x8*>(kb_base + kb * 8192 + k_rd[ks]);
+  };
+  auto qk_pipe = [&](auto bufc, f32x16 (&s)[2]) {
+    constexpr int BUF = decltype(bufc)::value;
+    const char* kb_base = lds + BUF * 2 * KV_TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[2 * (ks % KPF) + kb], qf[ks], ks == 0 ? negm : s[kb], 0, 0, 0);
+        if (ks + KPF < 8) ka[2 * (ks % KPF) + kb] = *reinterpret_cast<const bf16x8*>(kb_base + kb * 8192 + k_rd[ks + KPF]);
+      }
+    }
+  };
 
-    // ---- stage tile t+1 into the other buffer, issue the loads of tile t+2 ----
+  // ---- stage tile t+1 into the buffer tile t does not use, issue the loads of tile t+2 ----
+  auto stage = [&](auto bufc, int t) {
+    constexpr int BUF = decltype(bufc)::value;
     if (t + 1 < nt) {
       write_tile(IntC<BUF ^ 1>{});
       if (t + 2 < nt) load_tile(t + 2);
     }
+  };
 
-    // ---- mask keys past skv (last tile only) ----
-    if (ragged && t == nt - 1) {
+  // ---- online softmax: s holds (score - m); leaves P = exp2(s) as bf16 B-operand fragments ----
+  auto softmax = [&](int t, f32x16 (&s)[2], bf16x8 (&pf)[4]) {
+    if (ragged && t == nt - 1) {  // keys past skv (last tile only)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -234,27 +273,31 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AttnParams p) 
           if (key >= p.skv) s[kb][i] = -1e30f;
         }
     }
-
-    // ---- online softmax ----
     float mx = s[0][0];
 #pragma unroll
     for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[0][i]);
 #pragma unroll
     for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[1][i]);
     mx = half_swap_max(mx);
-    if (__any(mx > m_run)) {
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.c);
-      m_run = m_new;
+    // Rare path: some row's maximum grew by more than the threshold (always taken on tile 0, where
+    // it sets m to the tile's true row maximum).  Everything at the old scale -- O, l and this
+    // tile's not yet exponentiated scores -- moves to the new scale exactly once.
+    if (t == 0 || __any(mx > kRescaleThr)) {
+      const float delta = t == 0 ? mx : fmaxf(mx, 0.f);
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
       l_run *= alpha;
 #pragma unroll
       for (int db = 0; db < 4; ++db)
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[kb][i] -= delta;
+      const float nm = negm[0] - delta;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) negm[i] = nm;
     }
-    float neg_mc = -m_run * p.c;
-    asm volatile("" : "+v"(neg_mc));  // keep exp2(fma(s, c, -m c)) one FMA: no refactoring to (s - m) * c
-    bf16x8 pf[4];
     float lsum = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -263,17 +306,21 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AttnParams p) 
         bf16x8 f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][8 * sidx + j], p.c, neg_mc));
+          const float e = __builtin_amdgcn_exp2f(s[kb][8 * sidx + j]);
           lsum += e;
           f[j] = (__bf16)e;
         }
         pf[kb * 2 + sidx] = f;
       }
     l_run += lsum;
+  };
 
-    // ---- O^T += V^T P^T ----
+  // ---- O^T += V^T P^T for k-steps [KS0, KS1) against the tile in LDS buffer BUF ----
+  auto pv = [&](auto bufc, auto ks0c, auto ks1c, const bf16x8 (&pf)[4]) {
+    constexpr int BUF = decltype(bufc)::value;
+    const char* kb_base = lds + BUF * 2 * KV_TILE_BYTES;
 #pragma unroll
-    for (int ks4 = 0; ks4 < 4; ++ks4) {
+    for (int ks4 = decltype(ks0c)::value; ks4 < decltype(ks1c)::value; ++ks4) {
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
         const bf16x4 lo = tr_read(kb_base + v_rd[ks4][0] + 512 * db);
@@ -282,15 +329,59 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AttnParams p) 
         o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf[ks4], o[db], 0, 0, 0);
       }
     }
-    __syncthreads();
   };
 
-  // ---- prologue: K0/V0 -> LDS, K1/V1 in flight, Q fragments final before the loop ----
+  // VARIANT 0 tile body
+  auto tile_plain = [&](auto bufc, int t, f32x16 (&s)[2]) {
+    bf16x8 pf[4];
+    qk(bufc, s);
+    stage(bufc, t);
+    softmax(t, s, pf);
+    pv(bufc, IntC<0>{}, IntC<4>{}, pf);
+    __syncthreads();
+  };
+  // VARIANT 1 tile body: the barrier sits before the last four PV MFMAs; right after it the first
+  // K fragments of tile t+1 are requested.
+  auto tile_pipe = [&](auto bufc, int t, f32x16 (&s)[2]) {
+    constexpr int BUF = decltype(bufc)::value;
+    const char* kb_base = lds + BUF * 2 * KV_TILE_BYTES;
+    bf16x8 pf[4];
+    qk_pipe(bufc, s);
+    stage(bufc, t);
+    softmax(t, s, pf);
+    pv(bufc, IntC<0>{}, IntC<3>{}, pf);
+    bf16x8 va[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      const bf16x4 lo = tr_read(kb_base + v_rd[3][0] + 512 * db);
+      const bf16x4 hi = tr_read(kb_base + v_rd[3][1] + 512 * db);
+      va[db] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+    __syncthreads();  // every LDS read of tile t is back, tile t+1 is fully written
+    if (t + 1 < nt) k_prefetch(IntC<BUF ^ 1>{});
+#pragma unroll
+    for (int db = 0; db < 4; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[db], pf[3], o[db], 0, 0, 0);
+  };
+
+  // ---- prologue: K0/V0 -> LDS, K1/V1 in flight, Q fragments scaled and final before the loop ----
   load_tile(0);
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) {
-    u32x4 v = qraw[ks];
-    if (ROPE) v = rope_chunk(v, p.rope + (int64_t)qrow_c * HD, 8 * ks + 4 * h);
+    float f[8];
+    unpack8(qraw[ks], f);
+    if (ROPE) {
+      const float* cs = p.rope + (int64_t)qrow_c * HD + 8 * ks + 4 * h;
+      const f32x4 co = *reinterpret_cast<const f32x4*>(cs), si = *reinterpret_cast<const f32x4*>(cs + 64);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float a = f[2 * i], b = f[2 * i + 1];
+        f[2 * i] = a * co[i] - b * si[i];
+        f[2 * i + 1] = a * si[i] + b * co[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] *= p.c;
+    u32x4 v = pack8(f);
     asm volatile("" : "+v"(v));  // the wait for the Q loads lands here, not inside the tile loop
     qf[ks] = __builtin_bit_cast(bf16x8, v);
   }
@@ -298,12 +389,24 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AttnParams p) 
   if (nt > 1) load_tile(1);
   __syncthreads();
 
-  int t = 0;
-  for (; t + 1 < nt; t += 2) {
-    tile(IntC<0>{}, t);
-    tile(IntC<1>{}, t + 1);
+  f32x16 s[2];
+  {
+    int t = 0;
+    if (VARIANT == 1) {
+      k_prefetch(IntC<0>{});
+      for (; t + 1 < nt; t += 2) {
+        tile_pipe(IntC<0>{}, t, s);
+        tile_pipe(IntC<1>{}, t + 1, s);
+      }
+      if (t < nt) tile_pipe(IntC<0>{}, t, s);
+    } else {
+      for (; t + 1 < nt; t += 2) {
+        tile_plain(IntC<0>{}, t, s);
+        tile_plain(IntC<1>{}, t + 1, s);
+      }
+      if (t < nt) tile_plain(IntC<0>{}, t, s);
+    }
   }
-  if (t < nt) tile(IntC<0>{}, t);
 
   // ---- normalise and store: o[db][i] = O[q0 + r32][32 db + 8 (i>>2) + 4 h + (i&3)] ----
   const float inv = 1.0f / half_swap_sum(l_run);
@@ -352,12 +455,19 @@ extern "C" int lx2v_attn_fwd_bf16(const uint16_t* q, int64_t ldq, const uint16_t
   LX2V_REQUIRE(skv * ldk * 2 < (1LL << 32) && skv * ldv * 2 < (1LL << 32), LX2V_EUNSUP,
                "attn_fwd: K/V extent (skv * token stride) must stay below 4 GiB for 32-bit buffer offsets");
   hipStream_t st = (hipStream_t)stream;
-  if (rope_cos_sin != nullptr)
-    hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid, block, 0, st, p);
-  else if (skv <= 2048)
-    hipLaunchKernelGGL((attn_fwd_kernel<false, true>), grid, block, 0, st, p);
-  else
-    hipLaunchKernelGGL((attn_fwd_kernel<false, false>), grid, block, 0, st, p);
+  static const int variant = [] {  // tuning switch: LX2V_ATTN_VARIANT = 0 plain order, 1 pipelined LDS reads
+    const char* e = getenv("LX2V_ATTN_VARIANT");
+    return (e && atoi(e) == 0) ? 0 : 1;
+  }();
+#define LX2V_ATTN_LAUNCH(R, SK)                                                                  \
+  do {                                                                                           \
+    if (variant == 0) hipLaunchKernelGGL((attn_fwd_kernel<R, SK, 0>), grid, block, 0, st, p);    \
+    else hipLaunchKernelGGL((attn_fwd_kernel<R, SK, 1>), grid, block, 0, st, p);                 \
+  } while (0)
+  if (rope_cos_sin != nullptr) LX2V_ATTN_LAUNCH(true, false);
+  else if (skv <= 2048) LX2V_ATTN_LAUNCH(false, true);
+  else LX2V_ATTN_LAUNCH(false, false);
+#undef LX2V_ATTN_LAUNCH
   LX2V_CHECK_LAUNCH("attn_fwd");
   return LX2V_OK;
 }

@@ -220,6 +220,8 @@ int main(int argc, char** argv) {
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, 0));
   printf("device: %s  CUs=%d  clock=%d MHz\n", prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000);
+  if (!strcmp(what, "selfattn")) bench_attn(S, H, iters);
+  if (!strcmp(what, "gemm1")) bench_gemm(S, D, D, 0, iters);
   if (!strcmp(what, "attn") || !strcmp(what, "all")) {
     bench_attn(S, H, iters);
     bench_attn(S, H, iters, 512);
