@@ -20,81 +20,11 @@
 // Optional fused 3-axis RoPE: q and k are rotated (interleaved pairs, fp32) as they are loaded.
 #include <stdlib.h>
 
-#include "common.h"
+#include "attn_common.h"
+
+using namespace lx2v_attn;
 
 namespace {
-
-constexpr int HD = 128;       // head dim
-constexpr int QROWS = 256;    // query rows per workgroup
-constexpr int KVB = 64;       // keys per tile
-constexpr int NTHREADS = 512;
-constexpr int KV_TILE_BYTES = KVB * HD * 2;  // 16 KiB
-
-struct AttnParams {
-  const uint16_t* q;
-  const uint16_t* k;
-  const uint16_t* v;
-  uint16_t* out;
-  const float* rope;  // [tokens][128] cos(64) || sin(64), or null
-  int64_t ldq, ldk, ldv, ldo;
-  int sq, skv, heads, nqb;
-  float c;  // scale * log2(e)
-};
-
-LX2V_DEVICE int k_lds_off(int row, int ch) { return row * 256 + ((ch ^ (row & 15)) << 4); }
-LX2V_DEVICE int v_lds_off(int row, int ch) {
-  return 2048 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
-}
-
-typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-
-LX2V_DEVICE bf16x4 tr_read(const char* p) {
-  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p));
-}
-
-// rotate the 4 interleaved pairs of one 8-element chunk: pairs pair0..pair0+3 of table row `cs`
-LX2V_DEVICE u32x4 rope_chunk(u32x4 v, const float* __restrict__ cs, int pair0) {
-  float f[8];
-  unpack8(v, f);
-  const f32x4 co = *reinterpret_cast<const f32x4*>(cs + pair0);
-  const f32x4 si = *reinterpret_cast<const f32x4*>(cs + 64 + pair0);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float a = f[2 * i], b = f[2 * i + 1];
-    f[2 * i] = a * co[i] - b * si[i];
-    f[2 * i + 1] = a * si[i] + b * co[i];
-  }
-  return pack8(f);
-}
-
-LX2V_DEVICE float half_swap_max(float x) {
-  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-LX2V_DEVICE float half_swap_sum(float x) {
-  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
-// Wave-uniform buffer descriptor over [base, base + bytes): loads past the end return 0, which is
-// how key rows >= skv of the last tile become zero rows without any per-lane clamping.
-LX2V_DEVICE __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
-  const uint64_t a = reinterpret_cast<uint64_t>(base);
-  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
-  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
-  void* pb = reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
-  return __builtin_amdgcn_make_buffer_rsrc(pb, 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
-}
-
-template <int N>
-struct IntC {
-  static constexpr int value = N;
-};
-
-// Rescale threshold in log2 units: O and l are rescaled only on tiles where some row's running
-// maximum would grow by more than this, so P stays <= 2^kRescaleThr (bf16 keeps its relative
-// precision at any magnitude; O and l accumulate in fp32).
-constexpr float kRescaleThr = 6.0f;
 
 // SHORT_KV only gives the cross-attention launches (a few hundred keys) their own kernel symbol,
 // so per-kernel profiles separate them from the long self-attention launches.
@@ -148,7 +78,7 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AttnParams p) 
   f32x4 rcos[2], rsin[2];  // only live when ROPE
   // Loads only: nothing here may consume the loaded registers, or the wait for them would land
   // at issue time instead of one tile later.
-  auto load_tile = [&](int t) {
+  auto load_tile = [&](int t) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rs, k_vo[i], t * k_tile_bytes, 0));
@@ -160,7 +90,7 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AttnParams p) 
     }
   };
   // Rotate (ROPE) and write to LDS buffer BUF.
-  auto write_tile = [&](auto bufc) {
+  auto write_tile = [&](auto bufc) __attribute__((always_inline)) {
     constexpr int BUF = decltype(bufc)::value;
     char* base = lds + BUF * 2 * KV_TILE_BYTES;
 #pragma unroll
@@ -232,7 +162,7 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AttnParams p) 
   };
   constexpr int KPF = 2;  // VARIANT 1: k-steps of K fragments kept in flight ahead of their MFMAs
   bf16x8 ka[2 * KPF];     // [2 (ks % KPF) + kb]
-  auto k_prefetch = [&](auto bufc) {  // k-steps 0..KPF-1 of the tile in buffer BUF
+  auto k_prefetch = [&](auto bufc) __attribute__((always_inline)) {  // k-steps 0..KPF-1 of the tile in buffer BUF
     constexpr int BUF = decltype(bufc)::value;
     const char* kb_base = lds + BUF * 2 * KV_TILE_BYTES;
 #pragma unroll
@@ -254,7 +184,7 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AttnParams p) 
   };
 
   // ---- stage tile t+1 into the buffer tile t does not use, issue the loads of tile t+2 ----
-  auto stage = [&](auto bufc, int t) {
+  auto stage = [&](auto bufc, int t) __attribute__((always_inline)) {
     constexpr int BUF = decltype(bufc)::value;
     if (t + 1 < nt) {
       write_tile(IntC<BUF ^ 1>{});
@@ -452,19 +382,20 @@ extern "C" int lx2v_attn_fwd_bf16(const uint16_t* q, int64_t ldq, const uint16_t
   const int64_t nwg = (int64_t)p.nqb * heads;
   LX2V_REQUIRE(nwg < (1LL << 31), LX2V_EUNSUP, "attn_fwd: grid too large");
   const dim3 grid((unsigned)nwg), block(NTHREADS);
-  LX2V_REQUIRE(skv * ldk * 2 < (1LL << 32) && skv * ldv * 2 < (1LL << 32), LX2V_EUNSUP,
+  LX2V_REQUIRE((skv + 2 * KVB) * ldk * 2 < (1LL << 32) && (skv + 2 * KVB) * ldv * 2 < (1LL << 32), LX2V_EUNSUP,
                "attn_fwd: K/V extent (skv * token stride) must stay below 4 GiB for 32-bit buffer offsets");
   hipStream_t st = (hipStream_t)stream;
-  static const int variant = [] {  // tuning switch: LX2V_ATTN_VARIANT = 0 plain order, 1 pipelined LDS reads
+  // Tuning switch LX2V_ATTN_VARIANT: 0 = plain order, 1 (default) = pipelined K-fragment reads.
+  static const int variant = [] {
     const char* e = getenv("LX2V_ATTN_VARIANT");
     return (e && atoi(e) == 0) ? 0 : 1;
   }();
 #define LX2V_ATTN_LAUNCH(R, SK)                                                                  \
   do {                                                                                           \
-    if (variant == 0) hipLaunchKernelGGL((attn_fwd_kernel<R, SK, 0>), grid, block, 0, st, p);    \
-    else hipLaunchKernelGGL((attn_fwd_kernel<R, SK, 1>), grid, block, 0, st, p);                 \
+    if (variant == 0) hipLaunchKernelGGL((attn_fwd_kernel<R, SK, 0>), grid, block, 0, st, p);       \
+    else hipLaunchKernelGGL((attn_fwd_kernel<R, SK, 1>), grid, block, 0, st, p);                    \
   } while (0)
-  if (rope_cos_sin != nullptr) LX2V_ATTN_LAUNCH(true, false);
+  if (rope_cos_sin != nullptr) hipLaunchKernelGGL((attn_fwd_kernel<true, false, 0>), grid, block, 0, st, p);  // variant 1 would spill with the rotation registers
   else if (skv <= 2048) LX2V_ATTN_LAUNCH(false, true);
   else LX2V_ATTN_LAUNCH(false, false);
 #undef LX2V_ATTN_LAUNCH
