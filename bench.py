@@ -51,6 +51,20 @@ def block_flops(S, D, H, F, T=TEXT_LEN):
     return self_attn, cross, gemm
 
 
+def measured_traffic(S, heads_local):
+    """HBM-side bytes per self-attention launch from the committed PMC collection (profiles/),
+    or None when no collection matches this launch shape."""
+    path = os.path.join(ROOT, "profiles", "r01_attn_traffic.json")
+    try:
+        rec = json.load(open(path))
+    except OSError:
+        return None
+    w = rec.get("workload", {})
+    if w.get("tokens") == S and w.get("heads") == heads_local:
+        return rec.get("traffic_bytes_per_launch")
+    return None
+
+
 def default_layout(n):
     return {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (2, 4)}.get(n, (1, n))
 
@@ -257,7 +271,7 @@ def main():
             "step_tflops": step_flops / 1e12,
             "achieved_tflops_per_gpu": step_flops / s_per_step / 1e12 / world,
             "roofline": {"kernel": "attn_fwd_kernel (self-attention)", "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": measured_traffic(S_pad, H // seq_p),
                          "launch_ms": attn_ms, "flops_per_launch": attn_flops, "launches_timed": sum(len(t.events) for t in timers)},
         }
         if world == 1 and not args.no_cpu_baseline:
