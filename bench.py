@@ -165,15 +165,34 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if os.environ.get("LX2V_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+
+        faulthandler.dump_traceback_later(int(os.environ["LX2V_BENCH_WATCHDOG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # LX2V_SHARE_GPU=1 + LX2V_DIST_BACKEND=gloo: functional rehearsal of the N>1 path with every rank
+    # on GPU 0 (gloo moves CUDA tensors through the host); never used for reported numbers.
+    share_gpu = os.environ.get("LX2V_SHARE_GPU", "0") == "1"
+    backend = os.environ.get("LX2V_DIST_BACKEND", "nccl")
+    dev_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+            # rehearsal only: gloo's CUDA path can hang when a collective is issued behind pending GPU
+            # work of several processes sharing one GPU; drain the stream first
+            for name in ("all_to_all_single", "all_gather", "all_reduce"):
+                def _synced(*a, _fn=getattr(dist, name), **kw):
+                    torch.cuda.synchronize()
+                    return _fn(*a, **kw)
+                setattr(dist, name, _synced)
     cfg_p, seq_p = default_layout(world) if args.layout is None else tuple(int(v) for v in args.layout.lower().split("x"))
     assert cfg_p * seq_p == world and cfg_p in (1, 2)
 
@@ -216,9 +235,14 @@ def main():
     inf.set_scheduler(Sch())
     timers = [AttnTimer(W.blocks[i].compute_phases[0].self_attn_1) for i in range(layers)]
 
+    dbg = os.environ.get("LX2V_BENCH_DEBUG") == "1"
+
     def forward(which):
         pre = L.WanPreInferModuleOutput(embed=embed, grid_sizes=grid, x=x0.clone(), embed0=embed0, context=contexts[which])
         out = inf.infer(W, pre)  # [S_loc, 64]
+        if dbg:
+            torch.cuda.synchronize()
+            print(f"[rank {rank}] forward({which}) done, out finite={bool(torch.isfinite(out.float()).all())}", flush=True)
         if seq_p > 1:
             parts = [torch.empty_like(out) for _ in range(seq_p)]
             dist.all_gather(parts, out, group=seq_group)
@@ -265,7 +289,8 @@ def main():
             "metric": "s/denoise-step Wan2.1-T2V-14B 720p81f" if (args.model, args.res) == ("wan2.1-t2v-14b", "720p") else f"s/denoise-step {args.model} {args.res}81f",
             "value": s_per_step, "unit": "s/denoise-step", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": s_per_step * 1e3, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic latents/text/timestep embeddings, random-init weights of the named architecture",
+            "dtype": "bf16", "data": "synthetic latents/text/timestep embeddings, random-init weights of the named architecture"
+                    + ("" if (backend == "nccl" and not share_gpu) else f" [REHEARSAL: backend={backend} share_gpu={share_gpu}, not a measurement]"),
             "config": {"workload": f"{args.model} {args.res} x81f: {S} tokens, {layers} blocks + head, 2 CFG forwards per step, text len {TEXT_LEN}",
                        "parallelism": f"cfg_p{cfg_p} x seq_p{seq_p} (ulysses)", "tokens": S, "dim": D, "heads": H, "ffn_dim": F, "layers": layers},
             "step_tflops": step_flops / 1e12,
