@@ -355,6 +355,8 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AttnParams p) 
 
 }  // namespace
 
+int lx2v_attn_launch_w4(const lx2v_attn::AttnParams& p, hipStream_t st);  // attn_fwd_w4.hip
+
 extern "C" int lx2v_attn_fwd_bf16(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk,
                                   const uint16_t* v, int64_t ldv, uint16_t* out, int64_t ldo,
                                   int64_t sq, int64_t skv, int heads, int head_dim, float scale,
@@ -382,10 +384,21 @@ extern "C" int lx2v_attn_fwd_bf16(const uint16_t* q, int64_t ldq, const uint16_t
   const int64_t nwg = (int64_t)p.nqb * heads;
   LX2V_REQUIRE(nwg < (1LL << 31), LX2V_EUNSUP, "attn_fwd: grid too large");
   const dim3 grid((unsigned)nwg), block(NTHREADS);
-  LX2V_REQUIRE((skv + 2 * KVB) * ldk * 2 < (1LL << 32) && (skv + 2 * KVB) * ldv * 2 < (1LL << 32), LX2V_EUNSUP,
+  LX2V_REQUIRE((skv + 8 * KVB) * ldk * 2 < (1LL << 32) && (skv + 8 * KVB) * ldv * 2 < (1LL << 32), LX2V_EUNSUP,
                "attn_fwd: K/V extent (skv * token stride) must stay below 4 GiB for 32-bit buffer offsets");
   hipStream_t st = (hipStream_t)stream;
-  // Tuning switch LX2V_ATTN_VARIANT: 0 = plain order, 1 (default) = pipelined K-fragment reads.
+  // Kernel choice: the 4-wave kernel (one wave per SIMD) unless RoPE is fused or
+  // LX2V_ATTN_KERNEL=w8 asks for the 8-wave one.
+  static const bool use_w4 = [] {
+    const char* e = getenv("LX2V_ATTN_KERNEL");
+    return !(e && strcmp(e, "w8") == 0);
+  }();
+  if (rope_cos_sin == nullptr && use_w4) {
+    lx2v_attn_launch_w4(p, st);
+    LX2V_CHECK_LAUNCH("attn_fwd(w4)");
+    return LX2V_OK;
+  }
+  // Tuning switch LX2V_ATTN_VARIANT (8-wave kernel): 0 = plain order, 1 (default) = pipelined K-fragment reads.
   static const int variant = [] {
     const char* e = getenv("LX2V_ATTN_VARIANT");
     return (e && atoi(e) == 0) ? 0 : 1;

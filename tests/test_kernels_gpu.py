@@ -193,6 +193,22 @@ def test_attention_online_softmax_rescale_branch(cuda):
     assert cos(out, ref.float()) >= 0.9999
 
 
+@pytest.mark.parametrize("sq,skv", [(300, 100), (256, 257), (300, 1000), (520, 2200)])
+def test_attention_never_consumes_memory_past_kv(cuda, sq, skv):
+    """K and V sit in the middle of one allocation whose every other element is NaN: the rows the
+    kernel prefetches past the last key must come back as zeros, not as whatever follows the tensor."""
+    H, pad = 1, 512
+    q = _rand((sq, H, 128), 60)
+    k, v = _rand((skv, H, 128), 61), _rand((skv, H, 128), 62)
+    ref = R.sdpa(q.float(), k.float(), v.float())
+    arena = torch.full((2, pad + skv + pad, H, 128), float("nan"), dtype=torch.bfloat16, device=cuda)
+    arena[0, pad:pad + skv] = k.to(cuda)
+    arena[1, pad:pad + skv] = v.to(cuda)
+    out = hip.attn_fwd(q.to(cuda), arena[0, pad:pad + skv], arena[1, pad:pad + skv])
+    assert torch.isfinite(out).all()
+    assert cos(out, ref) >= 0.9999
+
+
 def test_attention_strided_inputs_and_fused_rope(cuda):
     S, H, d = 360, 2, 128
     qkv = _rand((S, 3 * H * d), 40)
