@@ -39,12 +39,13 @@ using namespace lx2v_attn;
 namespace {
 
 #ifndef W4_ABL
-#define W4_ABL 0  // timing ablations (results are wrong with any bit set): 1 softmax VALU, 2 fragment reads, 4 staging, 8 barrier, 16 maximum check
+#define W4_ABL 0  // timing ablations (results are wrong with any bit set): 1 softmax VALU, 2 fragment reads, 4 staging, 8 barrier, 16 maximum check, 32 K fragment reads, 64 V fragment reads, 128 exps, 256 softmax VALU other than exps
 #endif
 constexpr int W4_THREADS = 256;
 constexpr int RING = 4;                        // tiles per LDS ring
 constexpr int K_RING = 0;                      // LDS byte offset of K slot 0
 constexpr int V_RING = RING * KV_TILE_BYTES;   // same for V
+constexpr float kRescaleSum = 64.0f;             // 2^kRescaleThr
 constexpr int DMA_PER_GROUP = 8;               // DMA instructions a wave issues per tile (4 K + 4 V)
 
 
@@ -103,25 +104,30 @@ __global__ __launch_bounds__(W4_THREADS) void attn_fwd_w4_kernel(const AttnParam
   const u32x4 k_rs = descriptor(p.k + head * HD, (int64_t)p.skv * p.ldk * 2);
   const u32x4 v_rs = descriptor(p.v + head * HD, (int64_t)p.skv * p.ldv * 2);
   const int krow = 4 * wid + (lane >> 4);
-  const int k_vo = (int)(krow * p.ldk * 2) + (((lane & 15) ^ (krow & 15)) << 4);
   const int vrow = 8 * (wid >> 1) + ((lane >> 2) & 7);
-  const int v_vo = (int)(vrow * p.ldv * 2) + ((4 * (2 * (wid & 1) + (lane >> 5)) + ((lane & 3) ^ ((vrow >> 2) & 3))) << 4);
+  int k_vo[4], v_vo[4];  // piece i: 16 rows further
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    k_vo[i] = (int)((krow + 16 * i) * p.ldk * 2) + (((lane & 15) ^ (krow & 15)) << 4);
+    v_vo[i] = (int)((vrow + 16 * i) * p.ldv * 2) + ((4 * (2 * (wid & 1) + (lane >> 5)) + ((lane & 3) ^ ((vrow >> 2) & 3))) << 4);
+  }
   const uint32_t k_tile_bytes = (uint32_t)(KVB * p.ldk * 2), v_tile_bytes = (uint32_t)(KVB * p.ldv * 2);
-  const uint32_t k_q_bytes = k_tile_bytes / 4, v_q_bytes = v_tile_bytes / 4;  // 16 rows
-  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)lds);
-  // lane L of the wave: 16 bytes from base + voff + soff to LDS byte dst + 16 L
-  auto dma16 = [&](const u32x4& rs, int voff, uint32_t soff, uint32_t dst) __attribute__((always_inline)) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(rs), "s"(dst), "s"(soff) : "memory");
+  const uint32_t dma_base = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)lds) + 1024 * wid_u;
+  // lane L of the wave: 16 bytes from base + voff + soff to LDS byte dma_base + DST + 16 L.  Every
+  // instruction of a lone wave costs issue time, scalar ones included: M0 is set by one add and
+  // not restored (nothing else in this kernel uses it).
+  auto dma16 = [&](const u32x4& rs, int voff, uint32_t soff, auto dstc) __attribute__((always_inline)) {
+    const uint32_t base = dma_base;  // (a capture used only as an asm operand is not captured)
+    asm volatile("s_add_u32 m0, %2, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
+                 :: "v"(voff), "s"(rs), "s"(base), "s"(soff), "i"(decltype(dstc)::value) : "memory", "scc");
   };
-  auto dma_k = [&](int t, auto slotc, auto ic) __attribute__((always_inline)) {
+  auto dma_k = [&](int t, auto slotc, auto ic, uint32_t soff = 0) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
-    dma16(k_rs, k_vo, (uint32_t)t * k_tile_bytes + i * k_q_bytes, lds_base + K_RING + decltype(slotc)::value * KV_TILE_BYTES + 4096 * i + 1024 * wid_u);
+    dma16(k_rs, k_vo[i], (uint32_t)t * k_tile_bytes + soff, IntC<K_RING + decltype(slotc)::value * KV_TILE_BYTES + 4096 * i>{});
   };
-  auto dma_v = [&](int t, auto slotc, auto ic) __attribute__((always_inline)) {
+  auto dma_v = [&](int t, auto slotc, auto ic, uint32_t soff = 0) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
-    dma16(v_rs, v_vo, (uint32_t)t * v_tile_bytes + i * v_q_bytes, lds_base + V_RING + decltype(slotc)::value * KV_TILE_BYTES + 4096 * i + 1024 * wid_u);
+    dma16(v_rs, v_vo[i], (uint32_t)t * v_tile_bytes + soff, IntC<V_RING + decltype(slotc)::value * KV_TILE_BYTES + 4096 * i>{});
   };
 
   // ---- fragment read offsets inside one tile image (derivation: the 8-wave kernel) ----
@@ -143,16 +149,22 @@ __global__ __launch_bounds__(W4_THREADS) void attn_fwd_w4_kernel(const AttnParam
   // period's tile t fix every buffer: even steps read the K rows of half tile k+1 (k = 2t+PAR),
   // odd steps the V^T fragments of half tile k-1; m = s/2 is the k-step (K) or
   // (k-step within the half, d-block) pair (V).
+  auto frag_read_k = [&](auto parc, auto bufc, auto sc) __attribute__((always_inline)) -> u32x4 {
+    constexpr int PAR = decltype(parc)::value, BUF = decltype(bufc)::value, m = decltype(sc)::value >> 1;
+    constexpr int off = K_RING + (PAR == 0 ? BUF : (BUF + 1) % RING) * KV_TILE_BYTES + (PAR == 0 ? 8192 : 0);
+    return *reinterpret_cast<const u32x4*>(lds + off + k_rd[m]);
+  };
+  auto frag_read_v = [&](auto parc, auto bufc, auto sc, auto uc) __attribute__((always_inline)) -> bf16x4 {
+    constexpr int PAR = decltype(parc)::value, BUF = decltype(bufc)::value, m = decltype(sc)::value >> 1;
+    constexpr int off = (PAR == 0 ? (BUF + RING - 1) % RING : BUF) * KV_TILE_BYTES + 512 * (m & 3);  // + V_RING inside v_rd
+    constexpr int ks4 = (PAR == 0 ? 2 : 0) + (m >> 2);
+    return tr_read(lds + off + v_rd[ks4][decltype(uc)::value]);
+  };
   auto frag_read = [&](auto parc, auto bufc, auto sc) __attribute__((always_inline)) -> u32x4 {
-    constexpr int PAR = decltype(parc)::value, BUF = decltype(bufc)::value, s = decltype(sc)::value, m = s >> 1;
-    if constexpr ((s & 1) == 0) {
-      constexpr int off = K_RING + (PAR == 0 ? BUF : (BUF + 1) % RING) * KV_TILE_BYTES + (PAR == 0 ? 8192 : 0);
-      return *reinterpret_cast<const u32x4*>(lds + off + k_rd[m]);
+    if constexpr ((decltype(sc)::value & 1) == 0) {
+      return frag_read_k(parc, bufc, sc);
     } else {
-      constexpr int off = (PAR == 0 ? (BUF + RING - 1) % RING : BUF) * KV_TILE_BYTES + 512 * (m & 3);  // + V_RING inside v_rd
-      constexpr int ks4 = (PAR == 0 ? 2 : 0) + (m >> 2);
-      const bf16x4 lo = tr_read(lds + off + v_rd[ks4][0]);
-      const bf16x4 hi = tr_read(lds + off + v_rd[ks4][1]);
+      const bf16x4 lo = frag_read_v(parc, bufc, sc, IntC<0>{}), hi = frag_read_v(parc, bufc, sc, IntC<1>{});
       return __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     }
   };
@@ -191,11 +203,17 @@ __global__ __launch_bounds__(W4_THREADS) void attn_fwd_w4_kernel(const AttnParam
   };
 
   // Rare path, entered before any P of half tile k is used: move O, l, m, S(k) and the complete
-  // S(k+1) of block b to the new maximum and redo P(k).  MFMAs on these registers may have been
+  // S(k+1) of block b to the row maximum of S(k) (never downwards, except for half tile 0, whose
+  // maximum becomes m whatever its sign) and redo P(k).  MFMAs on these registers may have been
   // issued a few cycles ago and others follow right after, hence the explicit wait states.
-  auto fixup = [&](auto bc, f32x16& sc, f32x16& sn, u32x4 (&pc)[2], float delta, float& lsa, float& lsb) __attribute__((always_inline)) {
+  auto fixup = [&](auto bc, f32x16& sc, f32x16& sn, u32x4 (&pc)[2], bool first, float& ls) __attribute__((always_inline)) {
     constexpr int b = decltype(bc)::value;
     asm volatile("s_nop 7\n\ts_nop 7" : "+a"(o[b][0]), "+a"(o[b][1]), "+a"(o[b][2]), "+a"(o[b][3]), "+v"(sc), "+v"(sn));
+    float mxl = sc[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mxl = fmaxf(mxl, sc[i]);
+    const float mxc = half_swap_max(mxl);
+    const float delta = first ? mxc : fmaxf(mxc, 0.f);
     const float alpha = __builtin_amdgcn_exp2f(-delta);
     l_run[b] *= alpha;
     static_for<0, 4>([&](auto dbc) __attribute__((always_inline)) {  // one tuple at a time through the architectural file
@@ -207,8 +225,8 @@ __global__ __launch_bounds__(W4_THREADS) void attn_fwd_w4_kernel(const AttnParam
     const float nm = negm[b][0] - delta;
 #pragma unroll
     for (int i = 0; i < 16; ++i) negm[b][i] = nm;
-    float ls = 0.f;
     float e[16];
+    ls = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       sc[i] -= delta;
@@ -218,8 +236,6 @@ __global__ __launch_bounds__(W4_THREADS) void attn_fwd_w4_kernel(const AttnParam
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) pc[i >> 2][i & 3] = pack2(e[2 * i], e[2 * i + 1]);
-    lsa = ls;
-    lsb = 0.f;
     asm volatile("s_nop 1" : "+a"(o[b][0]), "+a"(o[b][1]), "+a"(o[b][2]), "+a"(o[b][3]), "+v"(negm[b]), "+v"(pc[0]), "+v"(pc[1]), "+v"(sn));
   };
 
@@ -231,54 +247,84 @@ __global__ __launch_bounds__(W4_THREADS) void attn_fwd_w4_kernel(const AttnParam
     f32x16 (&Sn)[2] = PAR == 0 ? s1 : s0;        // S(k+1): accumulated in this period
     u32x4 (&Pc)[2][2] = PAR == 0 ? pfa : pfb;    // P(k): produced
     u32x4 (&Pp)[2][2] = PAR == 0 ? pfb : pfa;    // P(k-1): consumed
-    float mx[2] = {-3e38f, -3e38f}, lsa[2] = {0.f, 0.f}, lsb[2] = {0.f, 0.f};
-    float ea = 0.f;
+    float lsa[2] = {0.f, 0.f}, lsb[2] = {0.f, 0.f};
+    float ea[16], eb[16];  // exps of step s (block s & 1, chunk s >> 1)
     const int key0 = t * KVB + 32 * PAR;
     if (key0 + 32 > p.skv) {  // wave-uniform: only the last real half tile and the zero tiles
       mask_half(Sc[0], key0);
       mask_half(Sc[1], key0);
     }
+    // DMA of this period: odd periods bring K(t+4) into the slot K(t) just left, even periods
+    // V(t+2) into the slot V(t-2) left at the previous barrier; four pieces each, on even steps
+    // (one fragment read instruction instead of two), before step 11 in the even periods so that
+    // the count at the barrier is the same on every trip.
+    const uint32_t dma_soff = PAR == 1 ? (uint32_t)(t + 4) * k_tile_bytes : (uint32_t)(t + 2) * v_tile_bytes;
+    bf16x4 vlo;
     static_for<0, 16>([&](auto sc) __attribute__((always_inline)) {
       constexpr int s = decltype(sc)::value, m = s >> 1;
       constexpr int bsm = s & 1, c = s >> 1;  // softmax chunk of this step: scores 2c, 2c+1 of block bsm
+      constexpr bool NO_READ = (W4_ABL & 2) || ((W4_ABL & 32) && (s & 1) == 0) || ((W4_ABL & 64) && (s & 1) == 1);
+      constexpr int dma_i = (s & 1) ? -1 : PAR == 1 ? ((s & 3) == 0 ? s >> 2 : -1) : (s == 0 ? 0 : s == 4 ? 1 : s == 8 ? 2 : s == 10 ? 3 : -1);
       const u32x4 f = ring[s & 3];
-      // ---- gap 1: MFMA of block 0, first half of the chunk ----
+      // ---- gap 1: MFMA of block 0 ----
       if constexpr ((s & 1) == 0) {
         if constexpr (m == 0) mfma_qk_first(Sn[0], f, qf[0][0], negm[0]);
         else mfma_qk(Sn[0], f, qf[0][m]);
       } else {
         mfma_pv(o[0][m & 3], f, Pp[0][m >> 2]);
       }
+      // The exps of this step's chunk are only issued here; their consumers (row sum, bf16 pack) run
+      // one step later, so that no instruction waits on a transcendental just issued: with a
+      // single wave on the SIMD nothing else would fill that wait.
       if constexpr (!(W4_ABL & 1)) {
-        const float a = Sc[bsm][2 * c], b2 = Sc[bsm][2 * c + 1];
-        mx[bsm] = fmaxf(mx[bsm], fmaxf(a, b2));
-        ea = __builtin_amdgcn_exp2f(a);
-        lsa[bsm] += ea;
+        if constexpr (W4_ABL & 128) ea[s] = Sc[bsm][2 * c];
+        else ea[s] = __builtin_amdgcn_exp2f(Sc[bsm][2 * c]);
+        if constexpr (W4_ABL & 256) asm volatile("" :: "v"(ea[s]));
+        else if constexpr (s > 0) {
+          constexpr int pc = (s - 1) >> 1;
+          lsa[bsm ^ 1] += ea[s - 1];
+          Pc[bsm ^ 1][pc >> 2][pc & 3] = pack2(ea[s - 1], eb[s - 1]);
+        }
+      }
+      if constexpr ((s & 1) == 1 && !NO_READ) {  // first of the two V^T reads of the fragment four steps on
+        if constexpr (s + 4 < 16) vlo = frag_read_v(parc, bufc, IntC<s + 4>{}, IntC<0>{});
+        else if constexpr (PAR == 0) vlo = frag_read_v(IntC<1>{}, bufc, IntC<s - 12>{}, IntC<0>{});
+        else vlo = frag_read_v(IntC<0>{}, IntC<(BUF + 1) % RING>{}, IntC<s - 12>{}, IntC<0>{});
+      }
+      if constexpr (dma_i >= 0 && !(W4_ABL & 4)) {
+        if constexpr (PAR == 1) dma_k(0, bufc, IntC<dma_i>{}, dma_soff);
+        else dma_v(0, IntC<(BUF + 2) % RING>{}, IntC<dma_i>{}, dma_soff);
       }
       __builtin_amdgcn_sched_barrier(0);
-      // ---- gap 2: MFMA of block 1, fragment refill, second half of the chunk, staging ----
+      // ---- gap 2: MFMA of block 1 ----
       if constexpr ((s & 1) == 0) {
         if constexpr (m == 0) mfma_qk_first(Sn[1], f, qf[1][0], negm[1]);
         else mfma_qk(Sn[1], f, qf[1][m]);
       } else {
         mfma_pv(o[1][m & 3], f, Pp[1][m >> 2]);
       }
-      if constexpr (W4_ABL & 2) asm volatile("" : "+v"(ring[s & 3]));
-      else if constexpr (s + 4 < 16) ring[s & 3] = frag_read(parc, bufc, IntC<s + 4>{});
-      else if constexpr (PAR == 0) ring[s & 3] = frag_read(IntC<1>{}, bufc, IntC<s - 12>{});
-      else ring[s & 3] = frag_read(IntC<0>{}, IntC<(BUF + 1) % RING>{}, IntC<s - 12>{});
-      if constexpr (!(W4_ABL & 1)) {
-        const float eb = __builtin_amdgcn_exp2f(Sc[bsm][2 * c + 1]);
-        lsb[bsm] += eb;
-        Pc[bsm][c >> 2][c & 3] = pack2(ea, eb);
+      if constexpr (NO_READ) {
+        asm volatile("" : "+v"(ring[s & 3]));
+      } else if constexpr ((s & 1) == 0) {
+        if constexpr (s + 4 < 16) ring[s & 3] = frag_read_k(parc, bufc, IntC<s + 4>{});
+        else if constexpr (PAR == 0) ring[s & 3] = frag_read_k(IntC<1>{}, bufc, IntC<s - 12>{});
+        else ring[s & 3] = frag_read_k(IntC<0>{}, IntC<(BUF + 1) % RING>{}, IntC<s - 12>{});
+      } else {
+        bf16x4 vhi;
+        if constexpr (s + 4 < 16) vhi = frag_read_v(parc, bufc, IntC<s + 4>{}, IntC<1>{});
+        else if constexpr (PAR == 0) vhi = frag_read_v(IntC<1>{}, bufc, IntC<s - 12>{}, IntC<1>{});
+        else vhi = frag_read_v(IntC<0>{}, IntC<(BUF + 1) % RING>{}, IntC<s - 12>{}, IntC<1>{});
+        ring[s & 3] = __builtin_bit_cast(u32x4, __builtin_shufflevector(vlo, vhi, 0, 1, 2, 3, 4, 5, 6, 7));
       }
-      if constexpr (PAR == 1 && s < 8 && !(W4_ABL & 4)) {  // the DMA group of this tile: K(t+4), V(t+3)
-        if constexpr (s < 4) dma_k(t + 4, bufc, IntC<s>{});
-        else dma_v(t + 3, IntC<(BUF + RING - 1) % RING>{}, IntC<s - 4>{});
+      if constexpr (!(W4_ABL & 1)) {
+        if constexpr (W4_ABL & 128) eb[s] = Sc[bsm][2 * c + 1];
+        else eb[s] = __builtin_amdgcn_exp2f(Sc[bsm][2 * c + 1]);
+        if constexpr (W4_ABL & 256) asm volatile("" :: "v"(eb[s]));
+        else if constexpr (s > 0) lsb[bsm ^ 1] += eb[s - 1];
       }
       if constexpr (PAR == 0 && s == 11 && !(W4_ABL & 8)) {
-        // K(t+1) and V(t) (the group issued three tiles ago) have landed, this wave's reads of
-        // K(t) and V(t-1) are back; after the barrier that holds for every wave.
+        // K(t+1) and V(t) (issued three tiles ago) have landed, this wave's reads of K(t) and
+        // V(t-1) are back; after the barrier that holds for every wave.
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0x0070 | ((2 * DMA_PER_GROUP) & 15) | (((2 * DMA_PER_GROUP) >> 4) << 14));  // vmcnt(16) lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
@@ -286,21 +332,23 @@ __global__ __launch_bounds__(W4_THREADS) void attn_fwd_w4_kernel(const AttnParam
       }
       __builtin_amdgcn_sched_barrier(0);
     });
-    // ---- maximum check of half tile k (the exps above must not sink below the branch).  Each
-    // lane holds the maximum over its 16 of the row's 32 keys; "any lane above the threshold" needs
-    // no exchange, the row maximum itself is formed inside the rare path.
-    asm volatile("" : "+v"(Pc[0][0]), "+v"(Pc[0][1]), "+v"(lsa[0]), "+v"(lsb[0]));
-    asm volatile("" : "+v"(Pc[1][0]), "+v"(Pc[1][1]), "+v"(lsa[1]), "+v"(lsb[1]));
-    const bool first = PAR == 0 && t == 0;  // half tile 0: m becomes its true row maximum
-    if (!(W4_ABL & 16) && __builtin_expect(first || __any(fmaxf(mx[0], mx[1]) > kRescaleThr), 0)) {
-      static_for<0, 2>([&](auto bc) __attribute__((always_inline)) {
-        constexpr int b = decltype(bc)::value;
-        const float mxc = half_swap_max(mx[b]);
-        fixup(bc, Sc[b], Sn[b], Pc[b], first ? mxc : fmaxf(mxc, 0.f), lsa[b], lsb[b]);
-      });
+    // ---- overflow check of half tile k, before any P(k) is used.  Every exp is positive, so a
+    // lane whose 16 exps sum to at most 2^kRescaleThr holds no P above that bound: no row maximum
+    // is tracked in the loop, the rare path forms it.  (The exps above must not sink below the branch.)
+    float t0 = lsa[0] + lsb[0], t1 = lsa[1] + lsb[1];
+    if constexpr (!(W4_ABL & (1 | 256))) {  // consumers of the last step's exps
+      t1 += ea[15] + eb[15];
+      Pc[1][1][3] = pack2(ea[15], eb[15]);
     }
-    l_run[0] += lsa[0] + lsb[0];
-    l_run[1] += lsa[1] + lsb[1];
+    asm volatile("" : "+v"(Pc[0][0]), "+v"(Pc[0][1]), "+v"(t0));
+    asm volatile("" : "+v"(Pc[1][0]), "+v"(Pc[1][1]), "+v"(t1));
+    const bool first = PAR == 0 && t == 0;  // half tile 0: m becomes its true row maximum
+    if (!(W4_ABL & 16) && __builtin_expect(first || __any(fmaxf(t0, t1) > kRescaleSum), 0)) {
+      fixup(IntC<0>{}, Sc[0], Sn[0], Pc[0], first, t0);
+      fixup(IntC<1>{}, Sc[1], Sn[1], Pc[1], first, t1);
+    }
+    l_run[0] += t0;
+    l_run[1] += t1;
   };
 
   // ---- prologue: Q fragments scaled and parked; DMA groups of tiles -4, -3, -2 (K0; K1, V0; K2,
