@@ -394,7 +394,8 @@ extern "C" int lx2v_attn_fwd_bf16(const uint16_t* q, int64_t ldq, const uint16_t
     return !(e && strcmp(e, "w8") == 0);
   }();
   if (rope_cos_sin == nullptr && use_w4) {
-    lx2v_attn_launch_w4(p, st);
+    const int rc = lx2v_attn_launch_w4(p, st);
+    if (rc != LX2V_OK) return rc;
     LX2V_CHECK_LAUNCH("attn_fwd(w4)");
     return LX2V_OK;
   }
