@@ -295,7 +295,7 @@ def main():
                        "parallelism": f"cfg_p{cfg_p} x seq_p{seq_p} (ulysses)", "tokens": S, "dim": D, "heads": H, "ffn_dim": F, "layers": layers},
             "step_tflops": step_flops / 1e12,
             "achieved_tflops_per_gpu": step_flops / s_per_step / 1e12 / world,
-            "roofline": {"kernel": "attn_fwd_kernel (self-attention)", "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
+            "roofline": {"kernel": "attn_fwd_w4_kernel<false> (self-attention)", "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": measured_traffic(S_pad, H // seq_p),
                          "launch_ms": attn_ms, "flops_per_launch": attn_flops, "launches_timed": sum(len(t.events) for t in timers)},
         }

@@ -75,6 +75,9 @@ struct RoundSync {
 };
 constexpr long long kRoundWaitTicks = 10000;  // 100 us of the 100 MHz wall clock
 
+// SHORT_KV only names a second symbol for short key sequences (cross-attention), so that kernel
+// profiles keep self- and cross-attention apart.
+template <bool SHORT_KV>
 __global__ __launch_bounds__(W4_THREADS) void attn_fwd_w4_kernel(const AttnParams p, const RoundSync rs) {
   __shared__ __attribute__((aligned(16))) char lds[2 * RING * KV_TILE_BYTES];
   if (rs.done != nullptr) {
@@ -476,6 +479,7 @@ int lx2v_attn_launch_w4(const lx2v_attn::AttnParams& p, hipStream_t st) {
       rs.cus_per_xcd = cus[dev];
     }
   }
-  hipLaunchKernelGGL(attn_fwd_w4_kernel, dim3((unsigned)nwg), dim3(W4_THREADS), 0, st, p, rs);
+  if (p.skv <= 2048) hipLaunchKernelGGL(attn_fwd_w4_kernel<true>, dim3((unsigned)nwg), dim3(W4_THREADS), 0, st, p, rs);
+  else hipLaunchKernelGGL(attn_fwd_w4_kernel<false>, dim3((unsigned)nwg), dim3(W4_THREADS), 0, st, p, rs);
   return LX2V_OK;
 }
