@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Seconds per denoising step of the Wan DiT hot path on MI355X (synthetic data, random-init weights).
 
-One "step" = one `WanModel.infer`-equivalent pass: a conditional and an unconditional DiT forward
-(every transformer block + the head) and the classifier-free-guidance combine.  At N=1 both
+One "step" = `scheduler.step_pre` -> `WanModel.infer` -> `scheduler.step_post` on real-shaped latents
+[16, 21, H/8, W/8]: a conditional and an unconditional DiT forward (patch embedding, timestep / text
+MLPs, every transformer block, the head, unpatchify), the classifier-free-guidance combine and the
+UniPC update.  At N=1 both
 forwards run back to back on the one GPU; at N>1 the ranks form a (cfg_p, seq_p) grid like the
 reference's device mesh: cfg_p=2 puts the two forwards on two rank groups (one all_gather of the
 prediction), seq_p>1 shards tokens Ulysses-style (one fused q|k|v all-to-all + one return
@@ -39,6 +41,8 @@ MODELS = {
 }
 GRIDS = {"720p": (21, 45, 80), "480p": (21, 30, 52)}  # (f, h, w) latent tokens for 81 frames, patch (1,2,2)
 TEXT_LEN = 512
+TEXT_DIM = 4096  # umT5-xxl features
+LATENT_CHANNELS = 16
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X
 GUIDE_SCALE = 5.0
 
@@ -70,11 +74,12 @@ def default_layout(n):
 
 
 def build_model(cfg, device, seed):
-    """Random-init weights of the named architecture, generated on the GPU block by block."""
+    """WanModel with random-init weights of the named architecture, generated on the GPU block by block."""
     import lightx2v_amd as L
 
     D, F = cfg["dim"], cfg["ffn_dim"]
-    W = L.WanTransformerWeights(cfg)
+    model = L.WanModel(cfg)
+    W = model.transformer_weights
     g = torch.Generator(device=device).manual_seed(seed)
 
     def rn(*shape, std=1.0, dtype=torch.bfloat16):
@@ -101,7 +106,13 @@ def build_model(cfg, device, seed):
           "head.modulation": rn(1, 2, D, std=1.0 / math.sqrt(D), dtype=torch.float32)}
     W.head.load(hw)
     W.head_modulation.load(hw)
-    return W
+    pw = {"patch_embedding.weight": rn(D, cfg["in_dim"], 1, 2, 2, std=0.05), "patch_embedding.bias": rn(D, std=0.02, dtype=torch.float32)}
+    for name, (o, i) in {"text_embedding.0": (D, TEXT_DIM), "text_embedding.2": (D, D), "time_embedding.0": (D, cfg["freq_dim"]),
+                         "time_embedding.2": (D, D), "time_projection.1": (6 * D, D)}.items():
+        pw[name + ".weight"] = rn(o, i, std=0.02)
+        pw[name + ".bias"] = rn(o, std=0.02, dtype=torch.float32)
+    model.pre_weight.load(pw)
+    return model
 
 
 class AttnTimer:
@@ -212,48 +223,38 @@ def main():
     if world > 1:
         cfg_idx, seq_idx, seq_group, cfg_group = ulysses.make_groups(cfg_p, seq_p)
     cfg = {"num_layers": layers, "num_heads": H, "dim": D, "ffn_dim": F, "task": "t2v", "model_cls": "wan2.1",
+           "in_dim": LATENT_CHANNELS, "out_dim": LATENT_CHANNELS, "freq_dim": 256, "infer_steps": 50, "sample_shift": 5.0,
+           "sample_guide_scale": GUIDE_SCALE, "enable_cfg": True, "run_device": "cuda",
+           "cfg_parallel": cfg_p > 1, "cfg_p_group": cfg_group,
            "seq_parallel": seq_p > 1, "seq_p_group": seq_group, "parallel": {"seq_p_size": seq_p, "cfg_p_size": cfg_p, "seq_p_attn_type": "hip_ulysses"}}
-    W = build_model(cfg, dev, seed=1234)  # same seed on every rank: weights are replicated
-    inf = L.WanTransformerInfer(cfg)
+    model = build_model(cfg, dev, seed=1234)  # same seed on every rank: weights are replicated
+    sch = L.WanScheduler(cfg)
+    model.set_scheduler(sch)
 
-    # synthetic step inputs (what pre_infer would hand over), token-sharded under seq_p
+    # synthetic step inputs: latents of the clip's shape and umT5-sized text features (cond / uncond)
     S_pad = S + (seq_p - S % seq_p) % seq_p
-    S_loc = S_pad // seq_p
-    table = L.shard_rope_table(L.build_rope_table(grid, D // H), seq_p, seq_idx).to(dev)
+    latent_shape = (LATENT_CHANNELS, grid[0], 2 * grid[1], 2 * grid[2])
     g = torch.Generator(device=dev).manual_seed(99)
-    x_full = torch.randn(S_pad, D, generator=g, device=dev, dtype=torch.float32)
-    x_full[S:] = 0
-    x0 = x_full[seq_idx * S_loc:(seq_idx + 1) * S_loc].to(torch.bfloat16).contiguous()
-    del x_full
-    contexts = [torch.randn(TEXT_LEN, D, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16) for _ in range(2)]  # cond, uncond
-    embed0 = 0.1 * torch.randn(6, D, generator=g, device=dev, dtype=torch.float32)
-    embed = 0.1 * torch.randn(1, D, generator=g, device=dev, dtype=torch.float32)
-
-    class Sch:
-        cos_sin = table
-
-    inf.set_scheduler(Sch())
-    timers = [AttnTimer(W.blocks[i].compute_phases[0].self_attn_1) for i in range(layers)]
+    sch.prepare(0, latent_shape, latents=torch.randn(*latent_shape, generator=g, device=dev, dtype=torch.float32))
+    inputs = {"text_encoder_output": {k: torch.randn(1, TEXT_LEN, TEXT_DIM, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
+                                      for k in ("context", "context_null")}}
+    timers = [AttnTimer(model.transformer_weights.blocks[i].compute_phases[0].self_attn_1) for i in range(layers)]
 
     dbg = os.environ.get("LX2V_BENCH_DEBUG") == "1"
-
-    def forward(which):
-        pre = L.WanPreInferModuleOutput(embed=embed, grid_sizes=grid, x=x0.clone(), embed0=embed0, context=contexts[which])
-        out = inf.infer(W, pre)  # [S_loc, 64]
-        if dbg:
-            torch.cuda.synchronize()
-            print(f"[rank {rank}] forward({which}) done, out finite={bool(torch.isfinite(out.float()).all())}", flush=True)
-        if seq_p > 1:
-            parts = [torch.empty_like(out) for _ in range(seq_p)]
-            dist.all_gather(parts, out, group=seq_group)
-            out = torch.cat(parts, dim=0)[:S]
-        return out.float()
+    step_no = [0]
 
     def step():
-        if cfg_p == 1:
-            cond, uncond = forward(0), forward(1)
-            return uncond + GUIDE_SCALE * (cond - uncond)
-        return ulysses.cfg_parallel_combine(forward(cfg_idx), cfg_group, GUIDE_SCALE)
+        i = step_no[0] % cfg["infer_steps"]
+        step_no[0] += 1
+        if i == 0 and step_no[0] > 1:  # more timed steps than the schedule has: start a new clip
+            sch.prepare(0, latent_shape, latents=sch.latents)
+        sch.step_pre(step_index=i)
+        model.infer(inputs)
+        sch.step_post()
+        if dbg:
+            torch.cuda.synchronize()
+            print(f"[rank {rank}] step {i} done, latents finite={bool(torch.isfinite(sch.latents).all())}", flush=True)
+        return sch.latents
 
     def fence():
         torch.cuda.synchronize()
@@ -289,9 +290,9 @@ def main():
             "metric": "s/denoise-step Wan2.1-T2V-14B 720p81f" if (args.model, args.res) == ("wan2.1-t2v-14b", "720p") else f"s/denoise-step {args.model} {args.res}81f",
             "value": s_per_step, "unit": "s/denoise-step", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": s_per_step * 1e3, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic latents/text/timestep embeddings, random-init weights of the named architecture"
+            "dtype": "bf16", "data": "synthetic latents and text features, random-init weights of the named architecture"
                     + ("" if (backend == "nccl" and not share_gpu) else f" [REHEARSAL: backend={backend} share_gpu={share_gpu}, not a measurement]"),
-            "config": {"workload": f"{args.model} {args.res} x81f: {S} tokens, {layers} blocks + head, 2 CFG forwards per step, text len {TEXT_LEN}",
+            "config": {"workload": f"{args.model} {args.res} x81f: {S} tokens, full denoise step (pre-infer, {layers} blocks + head, unpatchify) x 2 CFG forwards + CFG combine + UniPC update, text len {TEXT_LEN}",
                        "parallelism": f"cfg_p{cfg_p} x seq_p{seq_p} (ulysses)", "tokens": S, "dim": D, "heads": H, "ffn_dim": F, "layers": layers},
             "step_tflops": step_flops / 1e12,
             "achieved_tflops_per_gpu": step_flops / s_per_step / 1e12 / world,

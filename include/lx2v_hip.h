@@ -109,6 +109,47 @@ int lx2v_ulysses_pack_qkv_bf16(const uint16_t* q, int64_t ldq, const uint16_t* k
                                const uint16_t* v, int64_t ldv, uint16_t* out, int64_t rows,
                                int dim, int world, void* stream);
 
+/* ==== Denoise-step glue (around the blocks; all small) ====================================== */
+
+/* ---- latents -> rows of the patch-embedding GEMM ------------------------------------------
+ * latents fp32 [C, F, H, W] -> out bf16 [F*(H/2)*(W/2), 4*C], column (c, ph, pw): a conv3d with
+ * kernel = stride = (1,2,2) is then lx2v_gemm_bf16 against weight.reshape(D, 4*C).
+ * round_latents != 0 also overwrites `latents` with their bf16-rounded values (the reference
+ * casts its stored latents to bf16 in BaseScheduler.step_pre, lightx2v/models/schedulers/scheduler.py:16-19).
+ * Replaces weights.patch_embedding.apply + flatten/transpose
+ *                 lightx2v/models/networks/wan/infer/pre_infer.py:56,63-64
+ * (Conv3dWeight.apply  lightx2v/common/ops/conv/conv3d.py). */
+int lx2v_patchify_bf16(float* latents, uint16_t* out, int channels, int frames, int height,
+                       int width, int round_latents, void* stream);
+
+/* ---- head output -> latent-shaped prediction ----------------------------------------------
+ * y bf16 [S, 4*C] (column (ph, pw, c), row stride ldy) -> out fp32 [C, F, H, W].
+ * Replaces WanPostInfer.unpatchify + .float()
+ *                 lightx2v/models/networks/wan/infer/post_infer.py:17-31. */
+int lx2v_unpatchify_f32(const uint16_t* y, int64_t ldy, float* out, int channels, int frames,
+                        int height, int width, void* stream);
+
+/* ---- sinusoidal timestep embedding: out bf16 [dim] = cos(t*w_i) (dim/2) || sin(t*w_i) -------
+ * w_i = 10000^(-i/(dim/2)).  `t` is a HOST scalar.
+ * Replaces sinusoidal_embedding_1d  lightx2v/models/networks/wan/infer/utils.py:205-215. */
+int lx2v_timestep_embedding_bf16(float t, int dim, uint16_t* out, void* stream);
+
+/* ---- SiLU, bf16, out may alias x.  Replaces torch.nn.functional.silu at pre_infer.py:79,81. */
+int lx2v_silu_bf16(const uint16_t* x, uint16_t* out, int64_t n, void* stream);
+
+/* ---- out = sum_{k<terms} coef[k] * x[k], fp32, 1 <= terms <= 4 -----------------------------
+ * `x` (HOST array of device pointers) and `coef` (HOST array) are read before the call returns;
+ * out may alias any input; n % 4 == 0, 16-byte aligned tensors.
+ * The tensor arithmetic of the UniPC update (convert_model_output, multistep_uni_c_bh_update,
+ * multistep_uni_p_bh_update)  lightx2v/models/schedulers/wan/scheduler.py:172-188,200-386. */
+int lx2v_lincomb_f32(float* out, int64_t n, int terms, const float* const* x, const float* coef,
+                     void* stream);
+
+/* ---- classifier-free guidance: out = uncond + g * (cond - uncond), fp32 ---------------------
+ * Replaces lightx2v/models/networks/wan/model.py:433. */
+int lx2v_cfg_combine_f32(float* out, const float* cond, const float* uncond, float guide_scale,
+                         int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,5 +20,13 @@ from .wan_block import (  # noqa: F401,E402
     WanTransformerWeights,
 )
 from .rope_table import build_rope_table, shard_rope_table  # noqa: F401,E402
+from .wan_model import (  # noqa: F401,E402
+    WanModel,
+    WanPostInfer,
+    WanPreInfer,
+    WanPreWeights,
+    WanScheduler,
+    run_denoise_loop,
+)
 
 __version__ = "0.1.0"

@@ -1,0 +1,175 @@
+// Denoise-step glue kernels around the Wan DiT blocks (all bandwidth-bound and small next to the
+// blocks): latent -> patch-row gather for the patch-embedding GEMM, head output -> latent scatter
+// (unpatchify), sinusoidal timestep embedding, SiLU, and the fp32 tensor arithmetic of the
+// classifier-free-guidance combine and of the UniPC scheduler update.
+#include "common.h"
+
+namespace {
+
+inline unsigned ew_blocks(int64_t items) {
+  const int64_t b = (items + 255) / 256;
+  return (unsigned)(b < 1 ? 1 : (b > 65535 * 16 ? 65535 * 16 : b));
+}
+
+// latents fp32 [C, F, H, W] -> rows bf16 [F*(H/2)*(W/2), C*4], column = (c, ph, pw): the flattening
+// order of a conv3d weight [D, C, 1, 2, 2].  One thread = one (token, channel): reads two pairs of
+// adjacent floats, writes 8 contiguous bytes.  With `round_src` the latents are replaced by their
+// bf16-rounded values on the way (the reference keeps its latents in bf16 between steps).
+__global__ __launch_bounds__(256) void patchify_kernel(float* __restrict__ lat, uint16_t* __restrict__ out, int C, int F, int H, int W, int round_src) {
+  const int h2 = H >> 1, w2 = W >> 1;
+  const int64_t n = (int64_t)F * h2 * w2 * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    int64_t tok = i / C;
+    const int x = (int)(tok % w2);
+    tok /= w2;
+    const int y = (int)(tok % h2);
+    const int f = (int)(tok / h2);
+    float* src = lat + (((int64_t)c * F + f) * H + 2 * y) * W + 2 * x;
+    const f32x2 r0 = *reinterpret_cast<const f32x2*>(src);
+    const f32x2 r1 = *reinterpret_cast<const f32x2*>(src + W);
+    const u32x2 pk = {pack2(r0[0], r0[1]), pack2(r1[0], r1[1])};
+    *reinterpret_cast<u32x2*>(out + (i / C) * (C * 4) + c * 4) = pk;
+    if (round_src) {
+      *reinterpret_cast<f32x2*>(src) = f32x2{__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xffff0000u)};
+      *reinterpret_cast<f32x2*>(src + W) = f32x2{__uint_as_float(pk[1] << 16), __uint_as_float(pk[1] & 0xffff0000u)};
+    }
+  }
+}
+
+// head output bf16 [S, 4*C] with column = (ph, pw, c)  ->  fp32 [C, F, H, W]
+__global__ __launch_bounds__(256) void unpatchify_kernel(const uint16_t* __restrict__ y, int64_t ldy, float* __restrict__ out, int C, int F, int H, int W) {
+  const int h2 = H >> 1, w2 = W >> 1;
+  const int64_t n = (int64_t)C * F * H * w2;  // one thread = two horizontally adjacent outputs
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int x = (int)(i % w2);
+    int64_t r = i / w2;
+    const int yy = (int)(r % H);
+    r /= H;
+    const int f = (int)(r % F);
+    const int c = (int)(r / F);
+    const int64_t tok = ((int64_t)f * h2 + (yy >> 1)) * w2 + x;
+    const uint16_t* src = y + tok * ldy + ((yy & 1) * 2) * C + c;
+    const f32x2 v = {__uint_as_float((uint32_t)src[0] << 16), __uint_as_float((uint32_t)src[C] << 16)};
+    *reinterpret_cast<f32x2*>(out + (((int64_t)c * F + f) * H + yy) * W + 2 * x) = v;
+  }
+}
+
+// out[i] = cos(t * 10000^(-i/half)), out[half + i] = sin(...): the angle is formed in fp32 like the
+// reference does, its cosine and sine are evaluated in double (angles reach 1000 rad).
+__global__ void timestep_embedding_kernel(float t, int half, uint16_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= half) return;
+  const float freq = (float)pow(10000.0, -(double)((float)i / (float)half));
+  const float ang = t * freq;
+  const bf16x2 cs = {(__bf16)(float)cos((double)ang), (__bf16)(float)sin((double)ang)};
+  out[i] = __builtin_bit_cast(uint32_t, cs) & 0xffffu;
+  out[half + i] = __builtin_bit_cast(uint32_t, cs) >> 16;
+}
+
+__global__ __launch_bounds__(256) void silu_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = __uint_as_float((uint32_t)x[i] << 16);
+    const bf16x2 r = {(__bf16)(v / (1.0f + expf(-v))), (__bf16)0.f};
+    out[i] = __builtin_bit_cast(uint32_t, r) & 0xffffu;
+  }
+}
+
+struct LinComb {
+  const float* x[4];
+  float c[4];
+  int terms;
+};
+
+// out = sum_k c[k] * x[k] (fp32, left to right); out may alias any input
+__global__ __launch_bounds__(256) void lincomb_kernel(float* out, const LinComb lc, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 acc = *reinterpret_cast<const f32x4*>(lc.x[0] + 4 * i) * lc.c[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+      if (k < lc.terms) acc += *reinterpret_cast<const f32x4*>(lc.x[k] + 4 * i) * lc.c[k];
+    *reinterpret_cast<f32x4*>(out + 4 * i) = acc;
+  }
+}
+
+// out = uncond + g * (cond - uncond), the reference's own association
+__global__ __launch_bounds__(256) void cfg_combine_kernel(float* out, const float* cond, const float* uncond, float g, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const f32x4 c = *reinterpret_cast<const f32x4*>(cond + 4 * i), u = *reinterpret_cast<const f32x4*>(uncond + 4 * i);
+    f32x4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = u[j] + g * (c[j] - u[j]);  // three roundings, as torch evaluates it (this file is built without contraction)
+    *reinterpret_cast<f32x4*>(out + 4 * i) = r;
+  }
+}
+
+}  // namespace
+
+extern "C" int lx2v_patchify_bf16(float* latents, uint16_t* out, int channels, int frames, int height, int width, int round_latents, void* stream) {
+  LX2V_REQUIRE(latents && out, LX2V_EINVAL, "patchify: null tensor");
+  LX2V_REQUIRE(channels > 0 && frames > 0 && height > 0 && width > 0 && height % 2 == 0 && width % 2 == 0, LX2V_EINVAL,
+               "patchify: bad latent shape [%d,%d,%d,%d] (height and width must be even)", channels, frames, height, width);
+  LX2V_REQUIRE((reinterpret_cast<uintptr_t>(latents) & 7u) == 0 && (reinterpret_cast<uintptr_t>(out) & 7u) == 0, LX2V_EINVAL, "patchify: tensors must be 8-byte aligned");
+  const int64_t n = (int64_t)frames * (height / 2) * (width / 2) * channels;
+  hipLaunchKernelGGL(patchify_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, latents, out, channels, frames, height, width, round_latents);
+  LX2V_CHECK_LAUNCH("patchify");
+  return LX2V_OK;
+}
+
+extern "C" int lx2v_unpatchify_f32(const uint16_t* y, int64_t ldy, float* out, int channels, int frames, int height, int width, void* stream) {
+  LX2V_REQUIRE(y && out, LX2V_EINVAL, "unpatchify: null tensor");
+  LX2V_REQUIRE(channels > 0 && frames > 0 && height > 0 && width > 0 && height % 2 == 0 && width % 2 == 0, LX2V_EINVAL,
+               "unpatchify: bad latent shape [%d,%d,%d,%d] (height and width must be even)", channels, frames, height, width);
+  LX2V_REQUIRE(ldy >= 4 * (int64_t)channels, LX2V_EINVAL, "unpatchify: row stride smaller than 4*channels");
+  LX2V_REQUIRE((reinterpret_cast<uintptr_t>(out) & 7u) == 0, LX2V_EINVAL, "unpatchify: output must be 8-byte aligned");
+  const int64_t n = (int64_t)channels * frames * height * (width / 2);
+  hipLaunchKernelGGL(unpatchify_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, y, ldy, out, channels, frames, height, width);
+  LX2V_CHECK_LAUNCH("unpatchify");
+  return LX2V_OK;
+}
+
+extern "C" int lx2v_timestep_embedding_bf16(float t, int dim, uint16_t* out, void* stream) {
+  LX2V_REQUIRE(out, LX2V_EINVAL, "timestep_embedding: null tensor");
+  LX2V_REQUIRE(dim > 0 && dim % 2 == 0, LX2V_EINVAL, "timestep_embedding: dim=%d must be positive and even", dim);
+  const int half = dim / 2;
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((half + 63) / 64), dim3(64), 0, (hipStream_t)stream, t, half, out);
+  LX2V_CHECK_LAUNCH("timestep_embedding");
+  return LX2V_OK;
+}
+
+extern "C" int lx2v_silu_bf16(const uint16_t* x, uint16_t* out, int64_t n, void* stream) {
+  LX2V_REQUIRE(x && out, LX2V_EINVAL, "silu: null tensor");
+  LX2V_REQUIRE(n >= 0, LX2V_EINVAL, "silu: n=%lld", (long long)n);
+  if (n == 0) return LX2V_OK;
+  hipLaunchKernelGGL(silu_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, out, n);
+  LX2V_CHECK_LAUNCH("silu");
+  return LX2V_OK;
+}
+
+extern "C" int lx2v_lincomb_f32(float* out, int64_t n, int terms, const float* const* x, const float* coef, void* stream) {
+  LX2V_REQUIRE(out && x && coef, LX2V_EINVAL, "lincomb: null argument");
+  LX2V_REQUIRE(terms >= 1 && terms <= 4, LX2V_EINVAL, "lincomb: terms=%d must be 1..4", terms);
+  LX2V_REQUIRE(n >= 0 && n % 4 == 0, LX2V_EINVAL, "lincomb: n=%lld must be a multiple of 4", (long long)n);
+  LX2V_REQUIRE(lx2v_aligned16(out), LX2V_EINVAL, "lincomb: tensors must be 16-byte aligned");
+  LinComb lc;
+  lc.terms = terms;
+  for (int k = 0; k < 4; ++k) {
+    lc.x[k] = k < terms ? x[k] : x[0];
+    lc.c[k] = k < terms ? coef[k] : 0.f;
+    LX2V_REQUIRE(lc.x[k] != nullptr && lx2v_aligned16(lc.x[k]), LX2V_EINVAL, "lincomb: input %d is null or not 16-byte aligned", k);
+  }
+  if (n == 0) return LX2V_OK;
+  hipLaunchKernelGGL(lincomb_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, out, lc, n / 4);
+  LX2V_CHECK_LAUNCH("lincomb");
+  return LX2V_OK;
+}
+
+extern "C" int lx2v_cfg_combine_f32(float* out, const float* cond, const float* uncond, float guide_scale, int64_t n, void* stream) {
+  LX2V_REQUIRE(out && cond && uncond, LX2V_EINVAL, "cfg_combine: null tensor");
+  LX2V_REQUIRE(n >= 0 && n % 4 == 0, LX2V_EINVAL, "cfg_combine: n=%lld must be a multiple of 4", (long long)n);
+  LX2V_REQUIRE(lx2v_aligned16(out) && lx2v_aligned16(cond) && lx2v_aligned16(uncond), LX2V_EINVAL, "cfg_combine: tensors must be 16-byte aligned");
+  if (n == 0) return LX2V_OK;
+  hipLaunchKernelGGL(cfg_combine_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, out, cond, uncond, guide_scale, n / 4);
+  LX2V_CHECK_LAUNCH("cfg_combine");
+  return LX2V_OK;
+}

@@ -29,6 +29,12 @@ _SIGNATURES = {
     "lx2v_gemm_bf16": [_P, _I64, _I64, _I64, _P, _I64, _P, _P, _I64, _I64, _I64, _I64, _I, _P, _I64, _P, _P],
     "lx2v_attn_fwd_bf16": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I, _I, _F, _P, _P],
     "lx2v_ulysses_pack_qkv_bf16": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _I, _P],
+    "lx2v_patchify_bf16": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "lx2v_unpatchify_f32": [_P, _I64, _P, _I, _I, _I, _I, _P],
+    "lx2v_timestep_embedding_bf16": [_F, _I, _P, _P],
+    "lx2v_silu_bf16": [_P, _P, _I64, _P],
+    "lx2v_lincomb_f32": [_P, _I64, _I, _P, _P, _P],
+    "lx2v_cfg_combine_f32": [_P, _P, _P, _F, _I64, _P],
 }
 EXPORTS = tuple(_SIGNATURES) + ("lx2v_abi_version", "lx2v_last_error")
 
@@ -213,4 +219,75 @@ def ulysses_pack_qkv(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, world: i
     st = load().lx2v_ulysses_pack_qkv_bf16(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
                                            out.data_ptr(), rows, dim, world, _stream())
     _check(st, "lx2v_ulysses_pack_qkv_bf16")
+    return out
+
+
+# ------------------------------------------------------------------------------- step glue
+def _need_f32_cuda(name: str, t: torch.Tensor):
+    if not t.is_cuda:
+        raise Lx2vError(f"{name}: expected a GPU tensor, got device {t.device} (no CPU fallback exists)")
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise Lx2vError(f"{name}: expected contiguous float32, got {t.dtype} (contiguous={t.is_contiguous()})")
+
+
+def patchify(latents: torch.Tensor, round_latents: bool = False) -> torch.Tensor:
+    """fp32 latents [C, F, H, W] -> bf16 [F*(H/2)*(W/2), 4*C], columns (c, ph, pw).  With
+    `round_latents` the latents are rounded through bf16 in place as well."""
+    _need_f32_cuda("patchify.latents", latents)
+    c, f, h, w = latents.shape
+    out = torch.empty((f * (h // 2) * (w // 2), 4 * c), dtype=torch.bfloat16, device=latents.device)
+    _check(load().lx2v_patchify_bf16(latents.data_ptr(), out.data_ptr(), c, f, h, w, int(round_latents), _stream()), "lx2v_patchify_bf16")
+    return out
+
+
+def unpatchify(y: torch.Tensor, channels: int, frames: int, height: int, width: int) -> torch.Tensor:
+    """bf16 head output [S, 4*C] (columns (ph, pw, c)) -> fp32 [C, F, H, W]."""
+    _need_bf16_cuda("unpatchify.y", y)
+    if y.shape[0] < frames * (height // 2) * (width // 2) or y.shape[1] != 4 * channels:
+        raise Lx2vError(f"unpatchify: y {tuple(y.shape)} does not cover a [{channels},{frames},{height},{width}] latent")
+    out = torch.empty((channels, frames, height, width), dtype=torch.float32, device=y.device)
+    _check(load().lx2v_unpatchify_f32(y.data_ptr(), y.stride(0), out.data_ptr(), channels, frames, height, width, _stream()), "lx2v_unpatchify_f32")
+    return out
+
+
+def timestep_embedding(t: float, dim: int, device) -> torch.Tensor:
+    out = torch.empty((1, dim), dtype=torch.bfloat16, device=device)
+    _check(load().lx2v_timestep_embedding_bf16(float(t), dim, out.data_ptr(), _stream()), "lx2v_timestep_embedding_bf16")
+    return out
+
+
+def silu(x: torch.Tensor) -> torch.Tensor:
+    _need_bf16_cuda("silu.x", x)
+    if not x.is_contiguous():
+        raise Lx2vError("silu: x must be contiguous")
+    out = torch.empty_like(x)
+    _check(load().lx2v_silu_bf16(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "lx2v_silu_bf16")
+    return out
+
+
+def lincomb(terms, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """sum of coef * tensor over `terms` = [(coef, fp32 tensor), ...] (1..4 terms, same shape)."""
+    if not 1 <= len(terms) <= 4:
+        raise Lx2vError(f"lincomb: {len(terms)} terms, 1..4 supported")
+    first = terms[0][1]
+    for _, t in terms:
+        _need_f32_cuda("lincomb.x", t)
+        if t.shape != first.shape:
+            raise Lx2vError("lincomb: all tensors must have the same shape")
+    if out is None:
+        out = torch.empty_like(first)
+    ptrs = (ctypes.c_void_p * len(terms))(*[t.data_ptr() for _, t in terms])
+    coefs = (ctypes.c_float * len(terms))(*[float(c) for c, _ in terms])
+    _check(load().lx2v_lincomb_f32(out.data_ptr(), first.numel(), len(terms), ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(coefs, ctypes.c_void_p), _stream()),
+           "lx2v_lincomb_f32")
+    return out
+
+
+def cfg_combine(cond: torch.Tensor, uncond: torch.Tensor, guide_scale: float) -> torch.Tensor:
+    _need_f32_cuda("cfg_combine.cond", cond)
+    _need_f32_cuda("cfg_combine.uncond", uncond)
+    if cond.shape != uncond.shape:
+        raise Lx2vError("cfg_combine: shapes differ")
+    out = torch.empty_like(cond)
+    _check(load().lx2v_cfg_combine_f32(out.data_ptr(), cond.data_ptr(), uncond.data_ptr(), float(guide_scale), cond.numel(), _stream()), "lx2v_cfg_combine_f32")
     return out

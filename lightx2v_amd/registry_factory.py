@@ -72,6 +72,7 @@ ATTN_WEIGHT_REGISTER = Register("attn")
 RMS_WEIGHT_REGISTER = Register("rms")
 LN_WEIGHT_REGISTER = Register("ln")
 TENSOR_REGISTER = Register("tensor")
+CONV3D_WEIGHT_REGISTER = Register("conv3d")
 
 _ALL = {
     "MM_WEIGHT_REGISTER": MM_WEIGHT_REGISTER,
@@ -79,6 +80,7 @@ _ALL = {
     "RMS_WEIGHT_REGISTER": RMS_WEIGHT_REGISTER,
     "LN_WEIGHT_REGISTER": LN_WEIGHT_REGISTER,
     "TENSOR_REGISTER": TENSOR_REGISTER,
+    "CONV3D_WEIGHT_REGISTER": CONV3D_WEIGHT_REGISTER,
 }
 
 

@@ -1,0 +1,171 @@
+"""Generate tests/golden/step_*.npz by running the REFERENCE's own step glue (CPU, fp32).
+
+Same scaffolding as gen_golden.py (bare-namespace import of the reference, fp32 dtype switch).
+For a tiny Wan-shaped model it builds the reference's `WanPreWeights` / `WanPreInfer`,
+`WanTransformerWeights`-style blocks / `WanTransformerInfer`, `WanPostInfer` and `WanScheduler`,
+injects the synthetic checkpoint, runs the reference denoise loop (step_pre -> cond and uncond
+forwards -> CFG combine -> step_post, the order of default_runner.py:137-159), asserts that
+`oracle/wan_step_ref.py` reproduces every intermediate, and stores the expected tensors.
+
+Usage: python oracle/gen_golden_step.py [--ref /root/reference] [--out tests/golden]
+"""
+
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+
+from oracle import gen_golden as G  # noqa: E402
+from oracle import wan_block_ref as R  # noqa: E402
+from oracle import wan_step_ref as T  # noqa: E402
+
+
+def build_model(dim, ffn, layers, text_dim, seed):
+    model = {}
+    for i in range(layers):
+        model.update(R.make_block_weights(dim, ffn, seed=seed, block_index=i))
+    model.update(R.make_head_weights(dim, 64, seed=seed))
+    model.update(T.make_pre_weights(dim, 16, 256, text_dim, seed=seed))
+    return model
+
+
+def reference_objects(cfg, model, layers):
+    import lightx2v.common.ops  # noqa: F401
+    from lightx2v.models.networks.wan.infer.post_infer import WanPostInfer
+    from lightx2v.models.networks.wan.infer.pre_infer import WanPreInfer
+    from lightx2v.models.networks.wan.weights.pre_weights import WanPreWeights
+    from lightx2v.models.schedulers.wan.scheduler import WanScheduler
+
+    pre_w = WanPreWeights(cfg)
+    pre_w.patch_embedding.weight = model["patch_embedding.weight"]
+    pre_w.patch_embedding.bias = model["patch_embedding.bias"]
+    for attr, key in [("text_embedding_0", "text_embedding.0"), ("text_embedding_2", "text_embedding.2"), ("time_embedding_0", "time_embedding.0"),
+                      ("time_embedding_2", "time_embedding.2"), ("time_projection_1", "time_projection.1")]:
+        mm = getattr(pre_w, attr)
+        mm.weight = model[key + ".weight"].t()
+        mm.bias = model[key + ".bias"]
+    blocks = []
+    infer = None
+    for i in range(layers):
+        blk, infer = G._ref_block_objects(cfg, model, block_index=i)
+        blocks.append(blk)
+
+    class Head:  # the three attributes infer_non_blocks reads (transformer_infer.py:75-97)
+        pass
+
+    from lightx2v.utils.registry_factory import LN_WEIGHT_REGISTER, MM_WEIGHT_REGISTER, TENSOR_REGISTER
+
+    head = Head()
+    head.norm = LN_WEIGHT_REGISTER["Default"]()
+    head.norm.weight = head.norm.bias = None
+    head.head = MM_WEIGHT_REGISTER["Default"]("head.head.weight", "head.head.bias")
+    head.head.weight = model["head.head.weight"].t()
+    head.head.bias = model["head.head.bias"]
+    head.head_modulation = TENSOR_REGISTER["Default"]("head.modulation")
+    head.head_modulation.tensor = model["head.modulation"]
+    sch = WanScheduler(cfg)
+    pre = WanPreInfer(cfg)
+    post = WanPostInfer(cfg)
+    for o in (pre, post, infer):
+        o.set_scheduler(sch)
+    return pre_w, blocks, head, pre, infer, post, sch
+
+
+def run_case(name, latent_shape, dim, heads, ffn, layers, text_len, text_dim, steps, shift, guide, seed, out_dir):
+    cfg = {
+        "dim": dim, "num_heads": heads, "num_layers": layers, "ffn_dim": ffn, "in_dim": 16, "out_dim": 16, "freq_dim": 256, "text_len": text_len,
+        "task": "t2v", "model_cls": "wan2.1", "run_device": "cpu", "cpu_offload": False, "seq_parallel": False, "cfg_parallel": False,
+        "self_attn_1_type": "torch_sdpa", "cross_attn_1_type": "torch_sdpa", "cross_attn_2_type": "torch_sdpa", "modulate_type": "torch",
+        "rope_type": "torch", "infer_steps": steps, "target_video_length": 4 * (latent_shape[1] - 1) + 1, "sample_shift": shift,
+        "sample_guide_scale": guide, "enable_cfg": True, "feature_caching": "NoCaching",
+    }
+    model = build_model(dim, ffn, layers, text_dim, seed)
+    pre_w, blocks, head, pre, infer, post, sch = reference_objects(cfg, model, layers)
+    g = torch.Generator().manual_seed(seed * 7919 + 17)
+    context = torch.randn(text_len, text_dim, generator=g)
+    context_null = torch.randn(text_len, text_dim, generator=g)
+    inputs = {"text_encoder_output": {"context": context.unsqueeze(0), "context_null": context_null.unsqueeze(0)}}
+
+    sch.prepare(seed, latent_shape)
+    latents0 = sch.latents.clone()
+    infer.cos_sin = sch.cos_sin
+
+    def ref_forward(cond: bool):
+        sch.infer_condition = cond
+        out = pre.infer(pre_w, inputs)
+        x = out.x
+        for blk in blocks:
+            x = infer.infer_block(blk, x, out)
+        y = infer.infer_non_blocks(head, x, out.embed)
+        return post.infer(y, out)[0], out
+
+    mine = T.UniPC(steps, shift)
+    assert torch.equal(mine.sigmas, sch.sigmas) and torch.equal(mine.timesteps, sch.timesteps)
+    store = {"latents0": latents0.numpy(), "context": context.numpy(), "context_null": context_null.numpy(),
+             "sigmas": sch.sigmas.numpy(), "timesteps": sch.timesteps.numpy()}
+    lat = latents0
+    worst = 0.0
+    for i in range(steps):
+        sch.step_pre(step_index=i)
+        cond, out = ref_forward(True)
+        uncond, _ = ref_forward(False)
+        sch.noise_pred = uncond + sch.sample_guide_scale * (cond - uncond)
+        # --- restatement, same inputs ---
+        t = mine.timestep_input(i)
+        assert torch.equal(t, sch.timestep_input)
+        if i == 0:
+            x, embed, embed0, ctx, grid = T.pre_infer(model, lat, t, context)
+            sch.infer_condition = True
+            pre_out = pre.infer(pre_w, inputs)  # fresh: the blocks update pre_infer_out.x in place
+            d = max((x - pre_out.x).abs().max().item(), (embed - pre_out.embed).abs().max().item(), (embed0 - pre_out.embed0).abs().max().item(),
+                    (ctx - pre_out.context).abs().max().item())
+            assert d < 2e-5, f"pre_infer mismatch {d}"
+            assert grid == pre_out.grid_sizes.tuple
+            store.update(pre_x=x.numpy(), pre_embed=embed.numpy(), pre_embed0=embed0.numpy(), pre_context=ctx.numpy())
+        my_cond = T.forward(model, lat, t, context, heads, layers)
+        my_uncond = T.forward(model, lat, t, context_null, heads, layers)
+        d = max((my_cond - cond).abs().max().item(), (my_uncond - uncond).abs().max().item())
+        worst = max(worst, d)
+        assert d < 5e-5, f"forward mismatch at step {i}: {d}"
+        my_noise = T.cfg_combine(my_cond, my_uncond, guide)
+        sch.step_post()
+        lat = mine.step(i, my_noise, lat)
+        d = (lat - sch.latents).abs().max().item()
+        worst = max(worst, d)
+        assert d < 2e-4, f"scheduler mismatch at step {i}: {d}"
+        store[f"noise_pred_{i}"] = sch.noise_pred.numpy()
+        store[f"latents_{i + 1}"] = sch.latents.numpy()
+    # the scheduler alone, fed the reference's own noise predictions: must agree to rounding
+    solo = T.UniPC(steps, shift)
+    lat = latents0
+    for i in range(steps):
+        lat = solo.step(i, torch.from_numpy(store[f"noise_pred_{i}"]), lat)
+        d = (lat - torch.from_numpy(store[f"latents_{i + 1}"])).abs().max().item()
+        assert d < 2e-6 * max(1.0, lat.abs().max().item()), f"UniPC restatement differs at step {i}: {d}"
+    meta = dict(latent_shape=latent_shape, dim=dim, heads=heads, ffn=ffn, layers=layers, text_len=text_len, text_dim=text_dim, steps=steps,
+                shift=shift, guide=guide, seed=seed)
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), meta=np.array(repr(meta)), **store)
+    print(f"{name}: {steps} steps, worst |restatement - reference| = {worst:.3e}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
+    a = ap.parse_args()
+    G._install_reference(a.ref)
+    torch.manual_seed(0)
+    with torch.no_grad():
+        run_case("step_tiny_d256", (16, 3, 8, 12), 256, 2, 512, 2, 16, 128, 6, 5.0, 5.0, 3, a.out)
+        run_case("step_small_d512", (16, 2, 12, 16), 512, 4, 1024, 2, 32, 256, 4, 3.0, 4.0, 5, a.out)
+
+
+if __name__ == "__main__":
+    main()

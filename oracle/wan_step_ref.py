@@ -1,0 +1,227 @@
+"""CPU restatement (torch fp32) of the reference's denoise-step glue around the Wan DiT blocks.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, `__graft_entry__.smoke()` and the golden generator;
+the product path never touches this file.  Parity is pinned: `oracle/gen_golden_step.py` runs the
+reference's own `WanPreInfer`, `WanTransformerInfer`, `WanPostInfer` and `WanScheduler` and
+asserts this restatement agrees before writing `tests/golden/step_*.npz`.
+
+Restated pieces (reference file:line):
+  * sinusoidal timestep embedding      lightx2v/models/networks/wan/infer/utils.py:205-215
+  * pre-infer (patch embed, time/text MLPs)   .../wan/infer/pre_infer.py:27-126
+  * unpatchify                         .../wan/infer/post_infer.py:26-31
+  * one forward = pre -> blocks -> head -> unpatchify   .../wan/model.py:447-466
+  * CFG combine                        .../wan/model.py:433
+  * UniPC multistep scheduler (flow sigmas, order 2, bh2 corrector/predictor)
+                                       lightx2v/models/schedulers/wan/scheduler.py:49-76,126-434
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import wan_block_ref as R
+
+PATCH = (1, 2, 2)
+
+
+# --------------------------------------------------------------------------- synthetic checkpoint
+def make_pre_weights(dim: int, in_dim: int = 16, freq_dim: int = 256, text_dim: int = 4096, seed: int = 0, dtype=torch.float32):
+    """Checkpoint keys of `WanPreWeights` (weights/pre_weights.py:17-40), synthetic values."""
+    g = torch.Generator().manual_seed(seed * 1000003 + 424243)
+
+    def lin(o, i):
+        return (0.02 * torch.randn(o, i, generator=g)).to(dtype), (0.02 * torch.randn(o, generator=g)).to(dtype)
+
+    w = {}
+    w["patch_embedding.weight"] = (0.05 * torch.randn(dim, in_dim, *PATCH, generator=g)).to(dtype)
+    w["patch_embedding.bias"] = (0.02 * torch.randn(dim, generator=g)).to(dtype)
+    for name, (o, i) in {
+        "text_embedding.0": (dim, text_dim),
+        "text_embedding.2": (dim, dim),
+        "time_embedding.0": (dim, freq_dim),
+        "time_embedding.2": (dim, dim),
+        "time_projection.1": (6 * dim, dim),
+    }.items():
+        w[name + ".weight"], w[name + ".bias"] = lin(o, i)
+    return w
+
+
+# --------------------------------------------------------------------------- pre / post infer
+def sinusoidal_embedding_1d(dim: int, position: torch.Tensor) -> torch.Tensor:
+    """utils.py:205-215: [cos(p * 10000^(-i/half)) || sin(...)], i < half."""
+    half = dim // 2
+    position = position.type(torch.float32)
+    sinusoid = torch.outer(position, torch.pow(10000, -torch.arange(half).to(position).div(half)))
+    return torch.cat([torch.cos(sinusoid), torch.sin(sinusoid)], dim=1)
+
+
+def patchify(latents: torch.Tensor) -> torch.Tensor:
+    """[C, F, H, W] -> [F*(H/2)*(W/2), C*1*2*2]: row = token (f, h/2, w/2), column = (c, pf, ph, pw),
+    the flattening order of the conv3d weight [D, C, 1, 2, 2] (pre_infer.py:56,63-64)."""
+    c, f, h, w = latents.shape
+    x = latents.view(c, f, h // 2, 2, w // 2, 2)
+    return x.permute(1, 2, 4, 0, 3, 5).reshape(f * (h // 2) * (w // 2), c * 4)
+
+
+def pre_infer(pw: Dict[str, torch.Tensor], latents: torch.Tensor, t: torch.Tensor, context: torch.Tensor, freq_dim: int = 256):
+    """pre_infer.py:27-126 for task t2v.  Returns (x [S,D], embed [1,D], embed0 [6,D], context [T,D], grid)."""
+    dim = pw["patch_embedding.bias"].shape[0]
+    _, f, h, w = latents.shape
+    x = R.linear(patchify(latents), pw["patch_embedding.weight"].reshape(dim, -1), pw["patch_embedding.bias"])
+    embed = sinusoidal_embedding_1d(freq_dim, t.flatten())
+    embed = R.linear(embed, pw["time_embedding.0.weight"], pw["time_embedding.0.bias"])
+    embed = F.silu(embed)
+    embed = R.linear(embed, pw["time_embedding.2.weight"], pw["time_embedding.2.bias"])
+    embed0 = F.silu(embed)
+    embed0 = R.linear(embed0, pw["time_projection.1.weight"], pw["time_projection.1.bias"]).unflatten(1, (6, dim)).squeeze(0)
+    out = R.linear(context, pw["text_embedding.0.weight"], pw["text_embedding.0.bias"])
+    out = F.gelu(out, approximate="tanh")
+    ctx = R.linear(out, pw["text_embedding.2.weight"], pw["text_embedding.2.bias"])
+    return x, embed, embed0, ctx, (f // PATCH[0], h // PATCH[1], w // PATCH[2])
+
+
+def unpatchify(x: torch.Tensor, grid: Tuple[int, int, int], out_dim: int = 16) -> torch.Tensor:
+    """post_infer.py:26-31: [S, 1*2*2*c] -> [c, F, 2H', 2W'] (head columns ordered (pf, ph, pw, c))."""
+    x = x[: math.prod(grid)].view(*grid, *PATCH, out_dim)
+    x = torch.einsum("fhwpqrc->cfphqwr", x)
+    return x.reshape(out_dim, *[i * j for i, j in zip(grid, PATCH)])
+
+
+def forward(model: Dict[str, torch.Tensor], latents: torch.Tensor, t: torch.Tensor, context: torch.Tensor, num_heads: int, num_layers: int,
+            cos_sin=None) -> torch.Tensor:
+    """`_infer_cond_uncond` (model.py:447-466): one DiT forward -> noise prediction [16, F, H, W] fp32."""
+    x, embed, embed0, ctx, grid = pre_infer(model, latents, t, context)
+    if cos_sin is None:
+        cos_sin = R.build_cos_sin(grid, model["patch_embedding.bias"].shape[0] // num_heads)
+    for i in range(num_layers):
+        x = R.block_forward(x, embed0, ctx, model, cos_sin, num_heads, block_index=i)
+    y = R.head_forward(x, embed, model)
+    return unpatchify(y, grid, model["head.head.bias"].shape[0] // 4).float()
+
+
+def cfg_combine(cond: torch.Tensor, uncond: torch.Tensor, guide: float) -> torch.Tensor:
+    """model.py:433."""
+    return uncond + guide * (cond - uncond)
+
+
+# --------------------------------------------------------------------------- UniPC scheduler
+class UniPC:
+    """`WanScheduler` restated (scheduler.py): flow-matching sigmas with `sample_shift`, solver
+    order 2, bh2 ("B(h) = expm1(h)"), corrector on every step after the first.  Scalars are
+    computed exactly as the reference does (fp32 torch scalars from the fp32 sigma table)."""
+
+    def __init__(self, infer_steps: int, sample_shift: float, num_train_timesteps: int = 1000, solver_order: int = 2):
+        self.infer_steps = infer_steps
+        self.solver_order = solver_order
+        self.num_train_timesteps = num_train_timesteps
+        # prepare(): :55-72
+        alphas = np.linspace(1, 1 / num_train_timesteps, num_train_timesteps)[::-1].copy()
+        sigmas = torch.from_numpy(1.0 - alphas).to(dtype=torch.float32)
+        sigma_min, sigma_max = sigmas[-1].item(), sigmas[0].item()
+        # set_timesteps(): :139-167
+        s = np.linspace(sigma_max, sigma_min, infer_steps + 1).copy()[:-1]
+        s = sample_shift * s / (1 + (sample_shift - 1) * s)
+        self.timesteps = torch.from_numpy(s * num_train_timesteps).to(dtype=torch.int64)
+        self.sigmas = torch.from_numpy(np.concatenate([s, [0]]).astype(np.float32))
+        self.model_outputs: List[Optional[torch.Tensor]] = [None] * solver_order
+        self.last_sample = None
+        self.this_order = None
+        self.lower_order_nums = 0
+        self.step_index = 0
+
+    def timestep_input(self, step_index: int) -> torch.Tensor:
+        return torch.stack([self.timesteps[step_index]])  # step_pre(): :389-391
+
+    def _lambda(self, sigma):
+        return torch.log(1 - sigma) - torch.log(sigma)
+
+    def coefficients(self, step_index: int, order: int, corrector: bool):
+        """Scalar part of multistep_uni_{p,c}_bh_update (:200-279 / :281-386): returns
+        (a, b, c, rk, rho) with  x_t = a*x - b*m0 - c*res,  res built from rk / rho."""
+        if corrector:
+            sigma_t, sigma_s0 = self.sigmas[step_index], self.sigmas[step_index - 1]
+        else:
+            sigma_t, sigma_s0 = self.sigmas[step_index + 1], self.sigmas[step_index]
+        alpha_t = 1 - sigma_t
+        h = self._lambda(sigma_t) - self._lambda(sigma_s0)
+        rk = None
+        if order == 2:
+            si = step_index - 2 if corrector else step_index - 1
+            rk = (self._lambda(self.sigmas[si]) - self._lambda(sigma_s0)) / h
+        hh = -h
+        h_phi_1 = torch.expm1(hh)
+        B_h = torch.expm1(hh)
+        rho = None
+        if corrector:
+            if order == 1:
+                rho = torch.tensor([0.5])
+            else:
+                rks = torch.tensor([rk, 1.0])
+                Rm, b = [], []
+                h_phi_k = h_phi_1 / hh - 1
+                fact = 1
+                for i in range(1, order + 1):
+                    Rm.append(torch.pow(rks, i - 1))
+                    b.append(h_phi_k * fact / B_h)
+                    fact *= i + 1
+                    h_phi_k = h_phi_k / hh - 1 / fact
+                rho = torch.linalg.solve(torch.stack(Rm), torch.tensor(b))
+        return sigma_t / sigma_s0, alpha_t * h_phi_1, alpha_t * B_h, rk, rho
+
+    def step(self, step_index: int, noise_pred: torch.Tensor, latents: torch.Tensor) -> torch.Tensor:
+        """step_post(): :394-434.  Returns the next latents."""
+        model_output = noise_pred.to(torch.float32)
+        sample = latents.to(torch.float32)
+        use_corrector = step_index > 0 and self.last_sample is not None
+        x0 = sample - self.sigmas[step_index] * model_output  # convert_model_output(): :172-188
+        if use_corrector:
+            a, b, c, rk, rho = self.coefficients(step_index, self.this_order, corrector=True)
+            m0 = self.model_outputs[-1]
+            x_t_ = a * self.last_sample - b * m0
+            if self.this_order == 2:
+                corr = rho[0] * ((self.model_outputs[-2] - m0) / rk)
+            else:
+                corr = 0
+            sample = x_t_ - c * (corr + rho[-1] * (x0 - m0))
+        for i in range(self.solver_order - 1):
+            self.model_outputs[i] = self.model_outputs[i + 1]
+        self.model_outputs[-1] = x0
+        this_order = min(self.solver_order, self.infer_steps - step_index)
+        self.this_order = min(this_order, self.lower_order_nums + 1)
+        self.last_sample = sample
+        a, b, c, rk, _ = self.coefficients(step_index, self.this_order, corrector=False)
+        m0 = self.model_outputs[-1]
+        x_t_ = a * sample - b * m0
+        if self.this_order == 2:
+            pred = 0.5 * ((self.model_outputs[-2] - m0) / rk)
+        else:
+            pred = 0
+        prev = x_t_ - c * pred
+        if self.lower_order_nums < self.solver_order:
+            self.lower_order_nums += 1
+        return prev
+
+
+def sample_loop(model, latents0: torch.Tensor, context: torch.Tensor, context_null: torch.Tensor, num_heads: int, num_layers: int,
+                infer_steps: int, sample_shift: float, guide: float, round_latents=None):
+    """The reference's denoise loop (default_runner `run_main` + model.infer + scheduler): per step
+    step_pre -> cond / uncond forwards -> CFG -> step_post.  `round_latents`: the dtype the
+    reference casts the stored latents to in `step_pre` (BaseScheduler.step_pre, scheduler.py:16-19;
+    bf16 in production, None in the fp32 oracle run).  Returns (final latents, per-step latents)."""
+    sch = UniPC(infer_steps, sample_shift)
+    latents = latents0
+    traj = []
+    for i in range(infer_steps):
+        if round_latents is not None:
+            latents = latents.to(round_latents)
+        t = sch.timestep_input(i)
+        cond = forward(model, latents.float(), t, context, num_heads, num_layers)
+        uncond = forward(model, latents.float(), t, context_null, num_heads, num_layers)
+        latents = sch.step(i, cfg_combine(cond, uncond, guide), latents)
+        traj.append(latents)
+    return latents, traj

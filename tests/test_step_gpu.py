@@ -1,0 +1,117 @@
+"""GPU: step-glue kernels and the whole denoise loop through the C ABI, against the CPU
+restatement and the reference's golden trajectory.
+
+Tolerances: the gathers are exact (bf16 rounding of the same values); the MLPs are bf16 GEMMs
+against fp32 (cosine); the denoise loop reports the final-latent max relative error against the
+reference's fp32 trajectory, the north star's second numerics figure."""
+import pytest
+import torch
+
+import lightx2v_amd as L
+from lightx2v_amd import hip
+from oracle import wan_step_ref as T
+from tests.test_step_oracle import step_case
+from tests.util import cos, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(16, 1, 2, 2), (16, 3, 8, 12), (4, 2, 6, 10), (16, 5, 30, 52)])
+def test_patchify_unpatchify_exact(cuda, shape):
+    lat = torch.randn(*shape, generator=torch.Generator().manual_seed(5))
+    d = lat.to(cuda)
+    rows = hip.patchify(d)
+    assert torch.equal(rows.cpu(), T.patchify(lat).to(torch.bfloat16))
+    assert torch.equal(d.cpu(), lat)  # untouched without round_latents
+    rows2 = hip.patchify(d, round_latents=True)
+    assert torch.equal(rows2, rows) and torch.equal(d.cpu(), lat.to(torch.bfloat16).float())
+    c, f, h, w = shape
+    y = torch.randn(f * (h // 2) * (w // 2), 4 * c, generator=torch.Generator().manual_seed(6)).to(torch.bfloat16)
+    out = hip.unpatchify(y.to(cuda), c, f, h, w)
+    assert torch.equal(out.cpu(), T.unpatchify(y.float(), (f, h // 2, w // 2), c))
+
+
+@pytest.mark.parametrize("t", [999.0, 500.0, 1.0, 0.0])
+def test_timestep_embedding_and_silu(cuda, t):
+    ref = T.sinusoidal_embedding_1d(256, torch.tensor([t]))
+    got = hip.timestep_embedding(t, 256, cuda)
+    assert (got.float().cpu() - ref).abs().max().item() <= 4e-3  # bf16 rounding of values in [-1, 1]
+    x = torch.randn(1, 1000, generator=torch.Generator().manual_seed(int(t))).to(torch.bfloat16)
+    s = hip.silu(x.to(cuda))
+    assert (s.float().cpu() - torch.nn.functional.silu(x.float())).abs().max().item() <= 2e-2
+
+
+def test_lincomb_and_cfg_combine(cuda):
+    g = torch.Generator().manual_seed(9)
+    xs = [torch.randn(16, 3, 8, 12, generator=g) for _ in range(4)]
+    cs = [0.75, -1.25, 0.3, 2.0]
+    for k in range(1, 5):
+        got = hip.lincomb([(c, x.to(cuda)) for c, x in zip(cs[:k], xs[:k])])
+        ref = sum(c * x.double() for c, x in zip(cs[:k], xs[:k]))
+        assert (got.double().cpu() - ref).abs().max().item() <= 1e-5
+    a = xs[0].to(cuda)
+    hip.lincomb([(2.0, a), (1.0, xs[1].to(cuda))], out=a)  # aliasing an input
+    assert (a.cpu() - (2.0 * xs[0] + xs[1])).abs().max().item() <= 1e-5
+    got = hip.cfg_combine(xs[0].to(cuda), xs[1].to(cuda), 5.0)
+    assert torch.equal(got.cpu(), T.cfg_combine(xs[0], xs[1], 5.0))
+    with pytest.raises(hip.Lx2vError):
+        hip.lincomb([(1.0, xs[0].to(cuda))] * 5)
+
+
+def _model(meta, model, cuda, **kw):
+    cfg = {"dim": meta["dim"], "num_heads": meta["heads"], "num_layers": meta["layers"], "ffn_dim": meta["ffn"], "in_dim": 16, "out_dim": 16,
+           "freq_dim": 256, "task": "t2v", "infer_steps": meta["steps"], "sample_shift": meta["shift"], "sample_guide_scale": meta["guide"],
+           "enable_cfg": True, "run_device": "cuda"}
+    cfg.update(kw)
+    m = L.WanModel(cfg, weight_dict=dict(model))
+    m.to_cuda()
+    sch = L.WanScheduler(cfg)
+    m.set_scheduler(sch)
+    return m, sch
+
+
+def test_pre_infer_matches_reference(cuda):
+    rec, meta, model = step_case("step_tiny_d256")
+    m, sch = _model(meta, model, cuda)
+    sch.prepare(meta["seed"], meta["latent_shape"], latents=torch.from_numpy(rec["latents0"]))
+    sch.step_pre(0)
+    inputs = {"text_encoder_output": {"context": torch.from_numpy(rec["context"]).to(cuda), "context_null": torch.from_numpy(rec["context_null"]).to(cuda)}}
+    out = m.pre_infer.infer(m.pre_weight, inputs)
+    for got, key in [(out.x, "pre_x"), (out.embed, "pre_embed"), (out.embed0, "pre_embed0"), (out.context, "pre_context")]:
+        assert cos(got, torch.from_numpy(rec[key])) >= 0.9995, key
+    assert out.grid_sizes.tuple == (3, 4, 6)
+
+
+@pytest.mark.parametrize("name", ["step_tiny_d256", "step_small_d512"])
+def test_denoise_loop_against_reference_trajectory(cuda, name):
+    rec, meta, model = step_case(name)
+    inputs_host = {"context": torch.from_numpy(rec["context"]), "context_null": torch.from_numpy(rec["context_null"])}
+    inputs = {"text_encoder_output": {k: v.to(cuda) for k, v in inputs_host.items()}}
+    report = {}
+    for keep in (True, False):  # fp32 latents between steps / the reference's production bf16 rounding
+        m, sch = _model(meta, model, cuda, keep_latents_dtype_in_scheduler=keep)
+        sch.prepare(meta["seed"], meta["latent_shape"], latents=torch.from_numpy(rec["latents0"]))
+        for i in range(meta["steps"]):
+            sch.step_pre(i)
+            m.infer(inputs)
+            assert cos(sch.noise_pred, torch.from_numpy(rec[f"noise_pred_{i}"])) >= 0.999, (keep, i)
+            sch.step_post()
+        final = torch.from_numpy(rec[f"latents_{meta['steps']}"])
+        report[keep] = (rel_err(sch.latents, final), cos(sch.latents, final))
+    print(f"\n{name}: final-latent max-rel-err / cosine vs the reference fp32 trajectory: "
+          f"fp32 latents {report[True][0]:.3e} / {report[True][1]:.6f}; bf16-rounded latents {report[False][0]:.3e} / {report[False][1]:.6f}")
+    assert report[True][0] <= 3e-2 and report[True][1] >= 0.9995
+    assert report[False][0] <= 5e-2 and report[False][1] >= 0.999
+
+
+def test_scheduler_on_reference_noise_is_tight(cuda):
+    """UniPC alone, fed the reference's own noise predictions: only fp32 rounding separates them."""
+    rec, meta, model = step_case("step_tiny_d256")
+    m, sch = _model(meta, model, cuda, keep_latents_dtype_in_scheduler=True)
+    sch.prepare(meta["seed"], meta["latent_shape"], latents=torch.from_numpy(rec["latents0"]))
+    for i in range(meta["steps"]):
+        sch.step_pre(i)
+        sch.noise_pred = torch.from_numpy(rec[f"noise_pred_{i}"]).to(cuda)
+        sch.step_post()
+        ref = torch.from_numpy(rec[f"latents_{i + 1}"])
+        assert (sch.latents.cpu() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()), i
