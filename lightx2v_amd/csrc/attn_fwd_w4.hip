@@ -75,6 +75,22 @@ struct RoundSync {
 };
 constexpr long long kRoundWaitTicks = 10000;  // 100 us of the 100 MHz wall clock
 
+// The softmax VALU instructions are asm statements as well: their ORDER inside each MFMA gap is
+// part of the design (a lone wave issues in program order), and the compiler would otherwise hoist
+// exps above the MFMA they are meant to follow and gather the row-sum adds into one tree at the end
+// of the period.  None of them reads a register written by the statement just before it.
+LX2V_DEVICE float exp2_op(float x) {
+  float r;
+  asm volatile("v_exp_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+LX2V_DEVICE void add_op(float& acc, float x) { asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(x)); }
+LX2V_DEVICE uint32_t cvt_pk_op(float lo, float hi) {
+  uint32_t r;
+  asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
 // SHORT_KV only names a second symbol for short key sequences (cross-attention), so that kernel
 // profiles keep self- and cross-attention apart.
 template <bool SHORT_KV>
@@ -282,15 +298,16 @@ __global__ __launch_bounds__(W4_THREADS) void attn_fwd_w4_kernel(const AttnParam
     }
     // DMA of this period: odd periods bring K(t+4) into the slot K(t) just left, even periods
     // V(t+2) into the slot V(t-2) left at the previous barrier; four pieces each, on even steps
-    // (one fragment read instruction instead of two), before step 11 in the even periods so that
-    // the count at the barrier is the same on every trip.
+    // (one fragment read instruction instead of two): steps 0, 4, 8, 10 of the even periods (before
+    // their barrier, so that the count there is the same on every trip), steps 4, 8, 12, 14 of the
+    // odd ones (well after the barrier that released the slot).
     const uint32_t dma_soff = __builtin_amdgcn_readfirstlane(PAR == 1 ? (uint32_t)(t + 4) * k_tile_bytes : (uint32_t)(t + 2) * v_tile_bytes);
     bf16x4 vlo;
     static_for<0, 16>([&](auto sc) __attribute__((always_inline)) {
       constexpr int s = decltype(sc)::value, m = s >> 1;
       constexpr int bsm = s & 1, c = s >> 1;  // softmax chunk of this step: scores 2c, 2c+1 of block bsm
       constexpr bool NO_READ = (W4_ABL & 2) || ((W4_ABL & 32) && (s & 1) == 0) || ((W4_ABL & 64) && (s & 1) == 1);
-      constexpr int dma_i = (s & 1) ? -1 : PAR == 1 ? ((s & 3) == 0 ? s >> 2 : -1) : (s == 0 ? 0 : s == 4 ? 1 : s == 8 ? 2 : s == 10 ? 3 : -1);
+      constexpr int dma_i = PAR == 1 ? (s == 4 ? 0 : s == 8 ? 1 : s == 12 ? 2 : s == 14 ? 3 : -1) : (s == 0 ? 0 : s == 4 ? 1 : s == 8 ? 2 : s == 10 ? 3 : -1);
       const u32x4 f = ring[s & 3];
       // ---- gap 1: MFMA of block 0 ----
       if constexpr ((s & 1) == 0) {
@@ -304,12 +321,12 @@ __global__ __launch_bounds__(W4_THREADS) void attn_fwd_w4_kernel(const AttnParam
       // single wave on the SIMD nothing else would fill that wait.
       if constexpr (!(W4_ABL & 1)) {
         if constexpr (W4_ABL & 128) ea[s] = Sc[bsm][2 * c];
-        else ea[s] = __builtin_amdgcn_exp2f(Sc[bsm][2 * c]);
+        else ea[s] = exp2_op(Sc[bsm][2 * c]);
         if constexpr (W4_ABL & 256) asm volatile("" :: "v"(ea[s]));
         else if constexpr (s > 0) {
           constexpr int pc = (s - 1) >> 1;
-          lsa[bsm ^ 1] += ea[s - 1];
-          Pc[bsm ^ 1][pc >> 2][pc & 3] = pack2(ea[s - 1], eb[s - 1]);
+          add_op(lsa[bsm ^ 1], ea[s - 1]);
+          Pc[bsm ^ 1][pc >> 2][pc & 3] = cvt_pk_op(ea[s - 1], eb[s - 1]);
         }
       }
       if constexpr ((s & 1) == 1 && !NO_READ) {  // first of the two V^T reads of the fragment four steps on
@@ -344,15 +361,18 @@ __global__ __launch_bounds__(W4_THREADS) void attn_fwd_w4_kernel(const AttnParam
       }
       if constexpr (!(W4_ABL & 1)) {
         if constexpr (W4_ABL & 128) eb[s] = Sc[bsm][2 * c + 1];
-        else eb[s] = __builtin_amdgcn_exp2f(Sc[bsm][2 * c + 1]);
+        else eb[s] = exp2_op(Sc[bsm][2 * c + 1]);
         if constexpr (W4_ABL & 256) asm volatile("" :: "v"(eb[s]));
-        else if constexpr (s > 0) lsb[bsm ^ 1] += eb[s - 1];
+        else if constexpr (s > 0) add_op(lsb[bsm ^ 1], eb[s - 1]);
       }
       if constexpr (PAR == 0 && s == 11 && !(W4_ABL & 8)) {
-        // K(t+1) and V(t) (issued three tiles ago) have landed, this wave's reads of K(t) and
-        // V(t-1) are back; after the barrier that holds for every wave.
+        // K(t+1) and V(t) (issued three tiles ago) have landed; after the barrier that holds for
+        // every wave.  This wave's last reads of K(t) and V(t-1) were issued before this point but
+        // are not waited for: an issued LDS read completes within ~10^2 cycles whatever its wave
+        // does next, while the first DMA into those slots is issued 8 steps (>= 512 cycles) after the
+        // barrier and lands an L2 latency later still.
         asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_waitcnt(0x0070 | ((2 * DMA_PER_GROUP) & 15) | (((2 * DMA_PER_GROUP) >> 4) << 14));  // vmcnt(16) lgkmcnt(0)
+        __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * DMA_PER_GROUP) & 15) | (((2 * DMA_PER_GROUP) >> 4) << 14));  // vmcnt(16)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
       }
