@@ -199,10 +199,25 @@ def main():
             dist.init_process_group(backend)
             # rehearsal only: gloo's CUDA path can hang when a collective is issued behind pending GPU
             # work of several processes sharing one GPU; drain the stream first
+            # (and run "async" collectives synchronously: several outstanding gloo operations on CUDA
+            # tensors of processes sharing one GPU deadlock)
+            class _Done:
+                def wait(self):
+                    return True
+
             for name in ("all_to_all_single", "all_gather", "all_reduce"):
-                def _synced(*a, _fn=getattr(dist, name), **kw):
+                def _synced(*a, _fn=getattr(dist, name), _name=name, **kw):
+                    was_async = kw.pop("async_op", False)
                     torch.cuda.synchronize()
-                    return _fn(*a, **kw)
+                    if _name == "all_to_all_single":  # gloo's CUDA path also stalls on offset views: use whole tensors
+                        dst, src = a[0], a[1]
+                        tmp = torch.empty(dst.shape, dtype=dst.dtype, device=dst.device)
+                        out = _fn(tmp, src.clone(), *a[2:], **kw)
+                        dst.copy_(tmp)
+                        torch.cuda.synchronize()
+                    else:
+                        out = _fn(*a, **kw)
+                    return _Done() if was_async else out
                 setattr(dist, name, _synced)
     cfg_p, seq_p = default_layout(world) if args.layout is None else tuple(int(v) for v in args.layout.lower().split("x"))
     assert cfg_p * seq_p == world and cfg_p in (1, 2)

@@ -21,6 +21,9 @@ constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int NTHREADS = 512;
 constexpr int TILE_BYTES = BM * BK * 2;  // 32 KiB, same for A and W
 constexpr int GROUP_M = 8;               // tile rasterisation: 8 row-panels share one column sweep
+#ifndef GEMM_ABL
+#define GEMM_ABL 0  // timing ablations (wrong results): 1 no load wait, 2 no staging, 4 no barrier
+#endif
 
 struct GemmParams {
   const uint16_t* A;
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const GemmParams p)
 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    if (kt + 1 < nk && !(GEMM_ABL & 2)) stage(cur ^ 1, kt + 1);
     const char* la = lds + cur * 2 * TILE_BYTES;
     const char* lw = la + TILE_BYTES;
 #pragma unroll
@@ -148,8 +151,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const GemmParams p)
         for (int mt = 0; mt < 8; ++mt)
           acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (!(GEMM_ABL & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!(GEMM_ABL & 4)) __syncthreads();
   }
 
   // ---- epilogue: fp32 math on accumulators -> per-wave LDS image (bf16) -> row stores ----

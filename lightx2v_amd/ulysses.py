@@ -2,8 +2,13 @@
 
 Stands in for `UlyssesAttnWeight` (lightx2v/common/ops/attn/ulysses_attn.py:11-137) and its helpers
 `all2all_seq2head` / `all2all_head2seq` (lightx2v/common/ops/attn/utils/all2all.py:7-89) with the
-same result -- global token order is rank-major chunks, rank r attends heads r*H/N..(r+1)*H/N,
-output heads are ordered by source rank -- and a different data path:
+same result -- global token order is rank-major chunks, the output's heads are in global head
+order -- and a different data path:
+
+  * Heads are dealt to ranks in groups of H/(N*C), round-robin (group g -> rank g % N), not in
+    one contiguous run per rank: with C > 1 ("chunks") a rank attends its C groups one after the
+    other, and the all-to-all of the next group and the return of the previous one overlap the
+    attention of the current one (async collectives on RCCL's own stream).
 
   * q, k and v travel in ONE all-to-all (the reference issues three).  The send buffer is
     [dest rank][S/N][q|k|v][H/N*d], written by one pack kernel, so on arrival token (src, s) of
@@ -19,6 +24,7 @@ On MI355X every GPU pair has its own xGMI link, so an all-to-all drives all 7 li
 
 from __future__ import annotations
 
+import os
 from typing import Callable, Optional, Tuple
 
 import torch
@@ -36,9 +42,14 @@ class HipUlyssesAttnWeight(_AttnBase):
         kernel.  (Injectable so the exchange logic can be exercised with host tensors in tests.)"""
         super().__init__()
         self._pack = pack_fn or hip.ulysses_pack_qkv
+        # Head chunks per rank: the exchange of chunk c+1 (and the return of chunk c-1) overlaps the
+        # attention of chunk c.  1 = one exchange, no overlap.
+        self.chunks = max(1, int(os.environ.get("LX2V_ULYSSES_CHUNKS", "2")))
 
     # ---- exchange core -------------------------------------------------------------------------
     def _exchange_attend(self, q, k, v, attention_module, group, model_cls=None) -> Tuple[torch.Tensor, int, int, int]:
+        """Returns (back, segments, sl, seg): `back` is [segments][sl][seg] with the segments in
+        global head order, i.e. the logical [sl, H*d] output has columns [g*seg, (g+1)*seg) at back[g]."""
         if q.dim() == 4:
             q, k, v = (t.reshape(-1, t.shape[-2], t.shape[-1]) for t in (q, k, v))
         world = dist.get_world_size(group)
@@ -46,16 +57,29 @@ class HipUlyssesAttnWeight(_AttnBase):
         if heads % world != 0:
             raise ValueError(f"hip_ulysses: num_heads={heads} is not divisible by the sequence-parallel size {world}")
         hs = heads // world
+        chunks = max(c for c in range(1, self.chunks + 1) if hs % c == 0)
+        hc = hs // chunks
         dim = heads * d
-        send = self._pack(q.reshape(sl, dim), k.reshape(sl, dim), v.reshape(sl, dim), world)  # [world, sl, 3, hs*d]
+        # Head group g = heads [g*hc, (g+1)*hc) goes to rank g % world as its chunk g // world, so the
+        # pack kernel's natural order [g][sl][q|k|v][hc*d] is already [chunk][dest rank][...]: every
+        # chunk is one contiguous all-to-all, and the returned segments come back in head order.
+        send = self._pack(q.reshape(sl, dim), k.reshape(sl, dim), v.reshape(sl, dim), world * chunks).view(chunks, world, sl, 3, hc * d)
         recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send, group=group)
-        r = recv.view(world * sl, 3, hs, d)
-        attn = attention_module.apply(q=r[:, 0], k=r[:, 1], v=r[:, 2], cu_seqlens_q=None, cu_seqlens_kv=None,
-                                      max_seqlen_q=world * sl, max_seqlen_kv=world * sl, model_cls=model_cls)  # [S, hs*d]
-        back = torch.empty_like(attn)
-        dist.all_to_all_single(back, attn.contiguous(), group=group)  # [src][sl][hs*d]
-        return back, world, sl, hs * d
+        arrivals = [dist.all_to_all_single(recv[c], send[c], group=group, async_op=True) for c in range(chunks)]
+        back = torch.empty((chunks, world, sl, hc * d), dtype=send.dtype, device=send.device)  # [chunk][src rank][sl][hc*d]
+        returns, keep = [], []
+        for c in range(chunks):
+            # chunk c+1.. are still in flight while chunk c is attended; its output leaves while chunk c+1 is attended
+            arrivals[c].wait()
+            r = recv[c].view(world * sl, 3, hc, d)
+            attn = attention_module.apply(q=r[:, 0], k=r[:, 1], v=r[:, 2], cu_seqlens_q=None, cu_seqlens_kv=None,
+                                          max_seqlen_q=world * sl, max_seqlen_kv=world * sl, model_cls=model_cls)  # [S, hc*d]
+            attn = attn.contiguous()
+            keep.append(attn)
+            returns.append(dist.all_to_all_single(back[c], attn.view(world, sl, hc * d), group=group, async_op=True))
+        for w in returns:
+            w.wait()
+        return back, world * chunks, sl, hc * d
 
     # ---- reference-compatible entry ------------------------------------------------------------
     def apply(self, q, k, v, img_qkv_len, cu_seqlens_qkv, attention_module=None, seq_p_group=None, model_cls=None, use_fp8_comm=False):
@@ -64,15 +88,15 @@ class HipUlyssesAttnWeight(_AttnBase):
             raise NotImplementedError("hip_ulysses: fp8 payload exchange is not built yet")
         if int(cu_seqlens_qkv[-1]) != int(img_qkv_len) or q.shape[0] != img_qkv_len:
             raise NotImplementedError("hip_ulysses: a text part after the image tokens (HunyuanVideo layout) is not built yet")
-        back, world, sl, seg = self._exchange_attend(q, k, v, attention_module, seq_p_group, model_cls)
-        return back.view(world, sl, seg).permute(1, 0, 2).reshape(sl, world * seg)
+        back, nseg, sl, seg = self._exchange_attend(q, k, v, attention_module, seq_p_group, model_cls)
+        return back.view(nseg, sl, seg).permute(1, 0, 2).reshape(sl, nseg * seg)
 
     # ---- zero-copy form for the fused block runner ---------------------------------------------
     def apply_segmented(self, q, k, v, attention_module=None, seq_p_group=None, model_cls=None):
         """Returns (buffer, a_kseg, a_kseg_stride): logical [S/N, H*d] matrix whose K columns
-        [src*seg, (src+1)*seg) live at buffer + src*a_kseg_stride + row*seg."""
-        back, world, sl, seg = self._exchange_attend(q, k, v, attention_module, seq_p_group, model_cls)
-        return back.view(world * sl, seg)[:sl], seg, sl * seg
+        [g*seg, (g+1)*seg) live at buffer + g*a_kseg_stride + row*seg."""
+        back, nseg, sl, seg = self._exchange_attend(q, k, v, attention_module, seq_p_group, model_cls)
+        return back.view(nseg * sl, seg)[:sl], seg, sl * seg
 
 
 def make_groups(cfg_p_size: int, seq_p_size: int):

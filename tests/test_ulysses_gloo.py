@@ -55,8 +55,9 @@ def _worker(rank, world, port, cfg_p, seq_p, out_dir):
     buf, kseg, kstride = uly.apply_segmented(ql, kl, vl, attention_module=_OracleAttn(), seq_p_group=seq_group)
     flat = buf.reshape(-1) if buf.is_contiguous() else None
     base = buf.storage_offset()
-    storage = torch.as_strided(buf, (seq_p * Sl * kseg,), (1,), base)
-    logical = torch.stack([storage[s * kstride:(s * kstride + Sl * kseg)].view(Sl, kseg) for s in range(seq_p)], dim=1).reshape(Sl, seq_p * kseg)
+    nseg = H * d // kseg  # seq_p ranks x head chunks per rank
+    storage = torch.as_strided(buf, (nseg * Sl * kseg,), (1,), base)
+    logical = torch.stack([storage[s * kstride:(s * kstride + Sl * kseg)].view(Sl, kseg) for s in range(nseg)], dim=1).reshape(Sl, nseg * kseg)
     err2 = (logical - ref).abs().max().item()
     # H not divisible by N must raise, not floor silently
     raised = False
