@@ -112,15 +112,16 @@ int lx2v_ulysses_pack_qkv_bf16(const uint16_t* q, int64_t ldq, const uint16_t* k
 /* ==== Denoise-step glue (around the blocks; all small) ====================================== */
 
 /* ---- latents -> rows of the patch-embedding GEMM ------------------------------------------
- * latents fp32 [C, F, H, W] -> out bf16 [F*(H/2)*(W/2), 4*C], column (c, ph, pw): a conv3d with
- * kernel = stride = (1,2,2) is then lx2v_gemm_bf16 against weight.reshape(D, 4*C).
+ * latents fp32 [C, F, H, W] -> out bf16 [F*(H/2)*(W/2), 4*C] (row stride ldo >= 4*C; columns
+ * past 4*C are not written), column (c, ph, pw): a conv3d with kernel = stride = (1,2,2) is then
+ * lx2v_gemm_bf16 against weight.reshape(D, 4*C), both zero-padded to a K the GEMM accepts.
  * round_latents != 0 also overwrites `latents` with their bf16-rounded values (the reference
  * casts its stored latents to bf16 in BaseScheduler.step_pre, lightx2v/models/schedulers/scheduler.py:16-19).
  * Replaces weights.patch_embedding.apply + flatten/transpose
  *                 lightx2v/models/networks/wan/infer/pre_infer.py:56,63-64
  * (Conv3dWeight.apply  lightx2v/common/ops/conv/conv3d.py). */
-int lx2v_patchify_bf16(float* latents, uint16_t* out, int channels, int frames, int height,
-                       int width, int round_latents, void* stream);
+int lx2v_patchify_bf16(float* latents, uint16_t* out, int64_t ldo, int channels, int frames,
+                       int height, int width, int round_latents, void* stream);
 
 /* ---- head output -> latent-shaped prediction ----------------------------------------------
  * y bf16 [S, 4*C] (column (ph, pw, c), row stride ldy) -> out fp32 [C, F, H, W].

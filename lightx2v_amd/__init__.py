@@ -21,6 +21,7 @@ from .wan_block import (  # noqa: F401,E402
 )
 from .rope_table import build_rope_table, shard_rope_table  # noqa: F401,E402
 from .wan_model import (  # noqa: F401,E402
+    MultiModelStruct,
     WanModel,
     WanPostInfer,
     WanPreInfer,

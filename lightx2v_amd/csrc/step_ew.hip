@@ -15,7 +15,7 @@ inline unsigned ew_blocks(int64_t items) {
 // order of a conv3d weight [D, C, 1, 2, 2].  One thread = one (token, channel): reads two pairs of
 // adjacent floats, writes 8 contiguous bytes.  With `round_src` the latents are replaced by their
 // bf16-rounded values on the way (the reference keeps its latents in bf16 between steps).
-__global__ __launch_bounds__(256) void patchify_kernel(float* __restrict__ lat, uint16_t* __restrict__ out, int C, int F, int H, int W, int round_src) {
+__global__ __launch_bounds__(256) void patchify_kernel(float* __restrict__ lat, uint16_t* __restrict__ out, int64_t ldo, int C, int F, int H, int W, int round_src) {
   const int h2 = H >> 1, w2 = W >> 1;
   const int64_t n = (int64_t)F * h2 * w2 * C;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(float* __restrict__ lat, 
     const f32x2 r0 = *reinterpret_cast<const f32x2*>(src);
     const f32x2 r1 = *reinterpret_cast<const f32x2*>(src + W);
     const u32x2 pk = {pack2(r0[0], r0[1]), pack2(r1[0], r1[1])};
-    *reinterpret_cast<u32x2*>(out + (i / C) * (C * 4) + c * 4) = pk;
+    *reinterpret_cast<u32x2*>(out + (i / C) * ldo + c * 4) = pk;
     if (round_src) {
       *reinterpret_cast<f32x2*>(src) = f32x2{__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xffff0000u)};
       *reinterpret_cast<f32x2*>(src + W) = f32x2{__uint_as_float(pk[1] << 16), __uint_as_float(pk[1] & 0xffff0000u)};
@@ -105,13 +105,14 @@ __global__ __launch_bounds__(256) void cfg_combine_kernel(float* out, const floa
 
 }  // namespace
 
-extern "C" int lx2v_patchify_bf16(float* latents, uint16_t* out, int channels, int frames, int height, int width, int round_latents, void* stream) {
+extern "C" int lx2v_patchify_bf16(float* latents, uint16_t* out, int64_t ldo, int channels, int frames, int height, int width, int round_latents, void* stream) {
   LX2V_REQUIRE(latents && out, LX2V_EINVAL, "patchify: null tensor");
   LX2V_REQUIRE(channels > 0 && frames > 0 && height > 0 && width > 0 && height % 2 == 0 && width % 2 == 0, LX2V_EINVAL,
                "patchify: bad latent shape [%d,%d,%d,%d] (height and width must be even)", channels, frames, height, width);
   LX2V_REQUIRE((reinterpret_cast<uintptr_t>(latents) & 7u) == 0 && (reinterpret_cast<uintptr_t>(out) & 7u) == 0, LX2V_EINVAL, "patchify: tensors must be 8-byte aligned");
+  LX2V_REQUIRE(ldo >= 4 * (int64_t)channels && ldo % 4 == 0, LX2V_EINVAL, "patchify: row stride must be a multiple of 4 and >= 4*channels");
   const int64_t n = (int64_t)frames * (height / 2) * (width / 2) * channels;
-  hipLaunchKernelGGL(patchify_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, latents, out, channels, frames, height, width, round_latents);
+  hipLaunchKernelGGL(patchify_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, latents, out, ldo, channels, frames, height, width, round_latents);
   LX2V_CHECK_LAUNCH("patchify");
   return LX2V_OK;
 }

@@ -29,7 +29,7 @@ _SIGNATURES = {
     "lx2v_gemm_bf16": [_P, _I64, _I64, _I64, _P, _I64, _P, _P, _I64, _I64, _I64, _I64, _I, _P, _I64, _P, _P],
     "lx2v_attn_fwd_bf16": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I, _I, _F, _P, _P],
     "lx2v_ulysses_pack_qkv_bf16": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _I, _P],
-    "lx2v_patchify_bf16": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "lx2v_patchify_bf16": [_P, _P, _I64, _I, _I, _I, _I, _I, _P],
     "lx2v_unpatchify_f32": [_P, _I64, _P, _I, _I, _I, _I, _P],
     "lx2v_timestep_embedding_bf16": [_F, _I, _P, _P],
     "lx2v_silu_bf16": [_P, _P, _I64, _P],
@@ -230,13 +230,15 @@ def _need_f32_cuda(name: str, t: torch.Tensor):
         raise Lx2vError(f"{name}: expected contiguous float32, got {t.dtype} (contiguous={t.is_contiguous()})")
 
 
-def patchify(latents: torch.Tensor, round_latents: bool = False) -> torch.Tensor:
-    """fp32 latents [C, F, H, W] -> bf16 [F*(H/2)*(W/2), 4*C], columns (c, ph, pw).  With
-    `round_latents` the latents are rounded through bf16 in place as well."""
+def patchify(latents: torch.Tensor, round_latents: bool = False, pad_to: int = 0) -> torch.Tensor:
+    """fp32 latents [C, F, H, W] -> bf16 [F*(H/2)*(W/2), K], columns (c, ph, pw) then zeros up to
+    K = max(4*C, pad_to).  With `round_latents` the latents are rounded through bf16 in place as well."""
     _need_f32_cuda("patchify.latents", latents)
     c, f, h, w = latents.shape
-    out = torch.empty((f * (h // 2) * (w // 2), 4 * c), dtype=torch.bfloat16, device=latents.device)
-    _check(load().lx2v_patchify_bf16(latents.data_ptr(), out.data_ptr(), c, f, h, w, int(round_latents), _stream()), "lx2v_patchify_bf16")
+    k = max(4 * c, pad_to)
+    rows = f * (h // 2) * (w // 2)
+    out = torch.empty((rows, k), dtype=torch.bfloat16, device=latents.device) if k == 4 * c else torch.zeros((rows, k), dtype=torch.bfloat16, device=latents.device)
+    _check(load().lx2v_patchify_bf16(latents.data_ptr(), out.data_ptr(), k, c, f, h, w, int(round_latents), _stream()), "lx2v_patchify_bf16")
     return out
 
 

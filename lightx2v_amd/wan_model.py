@@ -54,7 +54,10 @@ class HipPatchEmbedWeight:
         w = weight_dict[self.weight_name]
         if tuple(w.shape[2:]) != PATCH_SIZE:
             raise ValueError(f"{self.weight_name}: kernel {tuple(w.shape[2:])}, expected {PATCH_SIZE}")
-        self.weight_nk = w.reshape(w.shape[0], -1).to(torch.bfloat16).contiguous()
+        w2 = w.reshape(w.shape[0], -1).to(torch.bfloat16)
+        k = w2.shape[1]
+        kp = (k + 63) // 64 * 64  # the GEMM's K granule: zero columns beyond 4*C (36 channels -> 144 -> 192)
+        self.weight_nk = torch.nn.functional.pad(w2, (0, kp - k)).contiguous()
         self.bias = None if self.bias_name is None else weight_dict[self.bias_name].to(torch.float32).contiguous()
 
     def _calculate_size(self):
@@ -78,15 +81,16 @@ class HipPatchEmbedWeight:
         return destination
 
     def apply(self, latents, round_latents=False):
-        return hip.gemm(hip.patchify(latents, round_latents=round_latents), self.weight_nk, self.bias)
+        return hip.gemm(hip.patchify(latents, round_latents=round_latents, pad_to=self.weight_nk.shape[1]), self.weight_nk, self.bias)
 
 
 class WanPreWeights(WeightModule):
     def __init__(self, config):
         super().__init__()
         config = with_defaults(config)
-        if config["task"] != "t2v":
-            raise NotImplementedError(f"task={config['task']!r}: the image-conditioned pre-infer branches are not built")
+        if config["task"] != "t2v" and not (config["task"] == "i2v" and not config.get("use_image_encoder", True)):
+            raise NotImplementedError(f"task={config['task']!r} with a CLIP image encoder: that pre-infer branch (img_emb.proj.*) is not built; "
+                                      "t2v and i2v with use_image_encoder=false (Wan2.2 two-expert) are")
         self.in_dim, self.dim, self.patch_size, self.config = config["in_dim"], config["dim"], PATCH_SIZE, config
         mm = MM_WEIGHT_REGISTER[config["dit_quant_scheme"]]
         self.add_module("patch_embedding", CONV3D_WEIGHT_REGISTER["hip-patch"]("patch_embedding.weight", "patch_embedding.bias", stride=PATCH_SIZE))
@@ -127,7 +131,15 @@ class WanPreInfer:
         c, f, h, w = latents.shape
         # the first forward of a step also rounds the stored latents through bf16 (see step_pre)
         round_now, sch.round_pending = getattr(sch, "round_pending", False), False
-        x = weights.patch_embedding.apply(latents, round_latents=round_now)
+        if self.task == "i2v":
+            # mask + VAE latents of the conditioning image ride along as extra input channels
+            # (pre_infer.py:37-53; in_dim = 16 + 20 for Wan2.2-A14B i2v)
+            y = inputs["image_encoder_output"]["vae_encoder_out"]
+            if round_now:
+                hip.patchify(latents, round_latents=True)
+            x = weights.patch_embedding.apply(torch.cat([latents, y.to(latents.dtype)], dim=0))
+        else:
+            x = weights.patch_embedding.apply(latents, round_latents=round_now)
         grid = (f // PATCH_SIZE[0], h // PATCH_SIZE[1], w // PATCH_SIZE[2])
         embed = hip.timestep_embedding(float(sch.timestep_input.flatten()[0]), self.freq_dim, latents.device)
         embed = weights.time_embedding_0.apply(embed)
@@ -378,7 +390,41 @@ class WanModel:
         return torch.cat(gathered, dim=0)
 
 
-def run_denoise_loop(model: WanModel, inputs, infer_steps: Optional[int] = None):
+class MultiModelStruct:
+    """Two experts sharing one scheduler (Wan2.2-A14B): the high-noise model runs while
+    timesteps[step_index] >= boundary * num_train_timesteps, the low-noise model after; each has its
+    own guide scale (`sample_guide_scale` is a pair).  Mirrors lightx2v/models/runners/wan/wan_runner.py:394-444
+    without the offload branches: both weight sets (2 x 28 GB in bf16) stay resident in HBM."""
+
+    def __init__(self, model_list, config, boundary=0.875, num_train_timesteps=1000):
+        self.model = model_list  # [high_noise_model, low_noise_model]
+        assert len(self.model) == 2, "MultiModelStruct only supports 2 models now."
+        self.config = config
+        self.boundary = boundary
+        self.boundary_timestep = self.boundary * num_train_timesteps
+        self.cur_model_index = -1
+        self.scheduler = None
+
+    def set_scheduler(self, shared_scheduler):
+        self.scheduler = shared_scheduler
+        for model in self.model:
+            model.set_scheduler(shared_scheduler)
+
+    def to_cuda(self):
+        for model in self.model:
+            model.to_cuda()
+
+    def infer(self, inputs):
+        self.get_current_model_index()
+        self.model[self.cur_model_index].infer(inputs)
+
+    def get_current_model_index(self):
+        high = float(self.scheduler.timesteps[self.scheduler.step_index]) >= self.boundary_timestep
+        self.cur_model_index = 0 if high else 1
+        self.scheduler.sample_guide_scale = self.config["sample_guide_scale"][self.cur_model_index]
+
+
+def run_denoise_loop(model, inputs, infer_steps: Optional[int] = None):
     """default_runner.py:137-169: step_pre -> model.infer -> step_post for every step."""
     sch = model.scheduler
     for step_index in range(sch.infer_steps if infer_steps is None else infer_steps):

@@ -27,12 +27,12 @@ from oracle import wan_block_ref as R  # noqa: E402
 from oracle import wan_step_ref as T  # noqa: E402
 
 
-def build_model(dim, ffn, layers, text_dim, seed):
+def build_model(dim, ffn, layers, text_dim, seed, in_dim=16):
     model = {}
     for i in range(layers):
         model.update(R.make_block_weights(dim, ffn, seed=seed, block_index=i))
     model.update(R.make_head_weights(dim, 64, seed=seed))
-    model.update(T.make_pre_weights(dim, 16, 256, text_dim, seed=seed))
+    model.update(T.make_pre_weights(dim, in_dim, 256, text_dim, seed=seed))
     return model
 
 
@@ -155,6 +155,64 @@ def run_case(name, latent_shape, dim, heads, ffn, layers, text_len, text_dim, st
     print(f"{name}: {steps} steps, worst |restatement - reference| = {worst:.3e}")
 
 
+def run_two_expert_case(name, latent_shape, dim, heads, ffn, layers, text_len, text_dim, steps, shift, guides, boundary, seed, out_dir):
+    """Wan2.2-A14B i2v shape of the loop: in_dim = 16 + 20 (latents + mask/VAE conditioning, no CLIP
+    branch), two experts sharing one scheduler.  The reference's WanPreInfer (task i2v,
+    use_image_encoder false), blocks, head, WanPostInfer and WanScheduler run per expert; the
+    expert switch is the restated MultiModelStruct rule (see wan_step_ref.sample_loop_two_experts)."""
+    cfg = {
+        "dim": dim, "num_heads": heads, "num_layers": layers, "ffn_dim": ffn, "in_dim": 36, "out_dim": 16, "freq_dim": 256, "text_len": text_len,
+        "task": "i2v", "model_cls": "wan2.2_moe", "use_image_encoder": False, "run_device": "cpu", "cpu_offload": False, "seq_parallel": False,
+        "cfg_parallel": False, "self_attn_1_type": "torch_sdpa", "cross_attn_1_type": "torch_sdpa", "cross_attn_2_type": "torch_sdpa",
+        "modulate_type": "torch", "rope_type": "torch", "infer_steps": steps, "target_video_length": 4 * (latent_shape[1] - 1) + 1,
+        "sample_shift": shift, "sample_guide_scale": list(guides), "enable_cfg": True, "feature_caching": "NoCaching",
+    }
+    models = [build_model(dim, ffn, layers, text_dim, seed + e, in_dim=36) for e in range(2)]
+    experts = [reference_objects(cfg, m, layers) for m in models]
+    sch = experts[0][6]
+    for pre_w, blocks, head, pre, infer, post, _ in experts:
+        for o in (pre, post, infer):
+            o.set_scheduler(sch)
+    g = torch.Generator().manual_seed(seed * 7919 + 29)
+    context = torch.randn(text_len, text_dim, generator=g)
+    context_null = torch.randn(text_len, text_dim, generator=g)
+    y = torch.randn(20, *latent_shape[1:], generator=g)
+    inputs = {"text_encoder_output": {"context": context.unsqueeze(0), "context_null": context_null.unsqueeze(0)},
+              "image_encoder_output": {"vae_encoder_out": y}}
+    sch.prepare(seed, latent_shape)
+    latents0 = sch.latents.clone()
+    for e in experts:
+        e[4].cos_sin = sch.cos_sin
+    store = {"latents0": latents0.numpy(), "context": context.numpy(), "context_null": context_null.numpy(), "y": y.numpy()}
+    picks = []
+    for i in range(steps):
+        sch.step_pre(step_index=i)
+        which = 0 if float(sch.timesteps[i]) >= boundary * 1000 else 1
+        pre_w, blocks, head, pre, infer, post, _ = experts[which]
+        preds = []
+        for cond in (True, False):
+            sch.infer_condition = cond
+            out = pre.infer(pre_w, inputs)
+            x = out.x
+            for blk in blocks:
+                x = infer.infer_block(blk, x, out)
+            preds.append(post.infer(infer.infer_non_blocks(head, x, out.embed), out)[0])
+        sch.noise_pred = preds[1] + guides[which] * (preds[0] - preds[1])
+        sch.step_post()
+        store[f"noise_pred_{i}"] = sch.noise_pred.numpy()
+        store[f"latents_{i + 1}"] = sch.latents.numpy()
+        picks.append(which)
+    assert 0 in picks and 1 in picks, picks
+    mine, traj, my_picks = T.sample_loop_two_experts(models, boundary, guides, latents0, context, context_null, heads, layers, steps, shift, y=y)
+    assert my_picks == picks
+    worst = max((a - torch.from_numpy(store[f"latents_{i + 1}"])).abs().max().item() for i, a in enumerate(traj))
+    assert worst < 2e-4, worst
+    meta = dict(latent_shape=latent_shape, dim=dim, heads=heads, ffn=ffn, layers=layers, text_len=text_len, text_dim=text_dim, steps=steps,
+                shift=shift, guides=list(guides), boundary=boundary, seed=seed, picks=picks)
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), meta=np.array(repr(meta)), **store)
+    print(f"{name}: {steps} steps, experts {picks}, worst |restatement - reference| = {worst:.3e}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -165,6 +223,7 @@ def main():
     with torch.no_grad():
         run_case("step_tiny_d256", (16, 3, 8, 12), 256, 2, 512, 2, 16, 128, 6, 5.0, 5.0, 3, a.out)
         run_case("step_small_d512", (16, 2, 12, 16), 512, 4, 1024, 2, 32, 256, 4, 3.0, 4.0, 5, a.out)
+        run_two_expert_case("step_moe_i2v_d256", (16, 3, 8, 12), 256, 2, 512, 1, 16, 128, 6, 5.0, (3.5, 3.0), 0.6, 7, a.out)
 
 
 if __name__ == "__main__":

@@ -68,10 +68,16 @@ def patchify(latents: torch.Tensor) -> torch.Tensor:
     return x.permute(1, 2, 4, 0, 3, 5).reshape(f * (h // 2) * (w // 2), c * 4)
 
 
-def pre_infer(pw: Dict[str, torch.Tensor], latents: torch.Tensor, t: torch.Tensor, context: torch.Tensor, freq_dim: int = 256):
-    """pre_infer.py:27-126 for task t2v.  Returns (x [S,D], embed [1,D], embed0 [6,D], context [T,D], grid)."""
+def pre_infer(pw: Dict[str, torch.Tensor], latents: torch.Tensor, t: torch.Tensor, context: torch.Tensor, freq_dim: int = 256,
+              y: Optional[torch.Tensor] = None):
+    """pre_infer.py:27-126 for task t2v, and for i2v without the CLIP branch (`use_image_encoder`
+    false, the Wan2.2 two-expert configuration): `y` = mask + VAE latents [C_y, F, H, W] is
+    concatenated to the latents along channels before the patch embedding (:37-53).
+    Returns (x [S,D], embed [1,D], embed0 [6,D], context [T,D], grid)."""
     dim = pw["patch_embedding.bias"].shape[0]
     _, f, h, w = latents.shape
+    if y is not None:
+        latents = torch.cat([latents, y], dim=0)
     x = R.linear(patchify(latents), pw["patch_embedding.weight"].reshape(dim, -1), pw["patch_embedding.bias"])
     embed = sinusoidal_embedding_1d(freq_dim, t.flatten())
     embed = R.linear(embed, pw["time_embedding.0.weight"], pw["time_embedding.0.bias"])
@@ -93,9 +99,9 @@ def unpatchify(x: torch.Tensor, grid: Tuple[int, int, int], out_dim: int = 16) -
 
 
 def forward(model: Dict[str, torch.Tensor], latents: torch.Tensor, t: torch.Tensor, context: torch.Tensor, num_heads: int, num_layers: int,
-            cos_sin=None) -> torch.Tensor:
+            cos_sin=None, y: Optional[torch.Tensor] = None) -> torch.Tensor:
     """`_infer_cond_uncond` (model.py:447-466): one DiT forward -> noise prediction [16, F, H, W] fp32."""
-    x, embed, embed0, ctx, grid = pre_infer(model, latents, t, context)
+    x, embed, embed0, ctx, grid = pre_infer(model, latents, t, context, y=y)
     if cos_sin is None:
         cos_sin = R.build_cos_sin(grid, model["patch_embedding.bias"].shape[0] // num_heads)
     for i in range(num_layers):
@@ -225,3 +231,25 @@ def sample_loop(model, latents0: torch.Tensor, context: torch.Tensor, context_nu
         latents = sch.step(i, cfg_combine(cond, uncond, guide), latents)
         traj.append(latents)
     return latents, traj
+
+
+def sample_loop_two_experts(models, boundary: float, guides, latents0: torch.Tensor, context: torch.Tensor, context_null: torch.Tensor,
+                            num_heads: int, num_layers: int, infer_steps: int, sample_shift: float, y: Optional[torch.Tensor] = None):
+    """Wan2.2-A14B style loop: `MultiModelStruct` (lightx2v/models/runners/wan/wan_runner.py:394-444)
+    picks the high-noise expert (models[0], guide scale guides[0]) while
+    timesteps[step] >= boundary * 1000 and the low-noise expert (models[1], guides[1]) after; both
+    share one scheduler.  (That class is restated from its source text: its module cannot be
+    imported in the golden generator's environment, its import chain needs packages that are absent;
+    everything it drives -- per-expert forwards, CFG, scheduler -- is pinned by the reference run.)
+    Returns (final latents, per-step latents, per-step expert index)."""
+    sch = UniPC(infer_steps, sample_shift)
+    latents, traj, picks = latents0, [], []
+    for i in range(infer_steps):
+        which = 0 if float(sch.timesteps[i]) >= boundary * sch.num_train_timesteps else 1
+        t = sch.timestep_input(i)
+        cond = forward(models[which], latents, t, context, num_heads, num_layers, y=y)
+        uncond = forward(models[which], latents, t, context_null, num_heads, num_layers, y=y)
+        latents = sch.step(i, cfg_combine(cond, uncond, guides[which]), latents)
+        traj.append(latents)
+        picks.append(which)
+    return latents, traj, picks

@@ -10,7 +10,7 @@ import torch
 import lightx2v_amd as L
 from lightx2v_amd import hip
 from oracle import wan_step_ref as T
-from tests.test_step_oracle import step_case
+from tests.test_step_oracle import moe_case, step_case
 from tests.util import cos, rel_err
 
 pytestmark = pytest.mark.gpu
@@ -115,3 +115,33 @@ def test_scheduler_on_reference_noise_is_tight(cuda):
         sch.step_post()
         ref = torch.from_numpy(rec[f"latents_{i + 1}"])
         assert (sch.latents.cpu() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()), i
+
+
+def test_two_expert_i2v_loop_against_reference_trajectory(cuda):
+    """Wan2.2-A14B shape of the loop: 36 input channels (latents + conditioning), high-/low-noise
+    experts switched at the boundary timestep, a guide scale per expert."""
+    rec, meta, models = moe_case()
+    cfg = {"dim": meta["dim"], "num_heads": meta["heads"], "num_layers": meta["layers"], "ffn_dim": meta["ffn"], "in_dim": 36, "out_dim": 16,
+           "freq_dim": 256, "task": "i2v", "use_image_encoder": False, "model_cls": "wan2.2_moe", "infer_steps": meta["steps"],
+           "sample_shift": meta["shift"], "sample_guide_scale": list(meta["guides"]), "enable_cfg": True, "run_device": "cuda",
+           "keep_latents_dtype_in_scheduler": True}
+    experts = [L.WanModel(cfg, weight_dict=dict(m)) for m in models]
+    mm = L.MultiModelStruct(experts, cfg, boundary=meta["boundary"])
+    mm.to_cuda()
+    sch = L.WanScheduler(cfg)
+    mm.set_scheduler(sch)
+    sch.prepare(meta["seed"], meta["latent_shape"], latents=torch.from_numpy(rec["latents0"]))
+    inputs = {"text_encoder_output": {"context": torch.from_numpy(rec["context"]).to(cuda), "context_null": torch.from_numpy(rec["context_null"]).to(cuda)},
+              "image_encoder_output": {"vae_encoder_out": torch.from_numpy(rec["y"]).to(cuda)}}
+    picks = []
+    for i in range(meta["steps"]):
+        sch.step_pre(i)
+        mm.infer(inputs)
+        picks.append(mm.cur_model_index)
+        assert cos(sch.noise_pred, torch.from_numpy(rec[f"noise_pred_{i}"])) >= 0.999, i
+        sch.step_post()
+    assert picks == meta["picks"]
+    final = torch.from_numpy(rec[f"latents_{meta['steps']}"])
+    err, c = rel_err(sch.latents, final), cos(sch.latents, final)
+    print(f"\ntwo-expert i2v loop: final-latent max-rel-err {err:.3e}, cosine {c:.6f}")
+    assert err <= 3e-2 and c >= 0.9995

@@ -12,6 +12,7 @@ from oracle import wan_step_ref as T
 from tests.util import load_golden
 
 STEP_CASES = ["step_tiny_d256", "step_small_d512"]
+MOE_CASE = "step_moe_i2v_d256"
 
 
 def step_case(name):
@@ -23,6 +24,60 @@ def step_case(name):
     model.update(R.make_head_weights(meta["dim"], 64, seed=meta["seed"]))
     model.update(T.make_pre_weights(meta["dim"], 16, 256, meta["text_dim"], seed=meta["seed"]))
     return rec, meta, model
+
+
+def moe_case(name=MOE_CASE):
+    rec = load_golden(name)
+    meta = ast.literal_eval(str(rec["meta"]))
+    models = []
+    for e in range(2):
+        m = {}
+        for i in range(meta["layers"]):
+            m.update(R.make_block_weights(meta["dim"], meta["ffn"], seed=meta["seed"] + e, block_index=i))
+        m.update(R.make_head_weights(meta["dim"], 64, seed=meta["seed"] + e))
+        m.update(T.make_pre_weights(meta["dim"], 36, 256, meta["text_dim"], seed=meta["seed"] + e))
+        models.append(m)
+    return rec, meta, models
+
+
+def test_two_expert_loop_matches_reference_trajectory():
+    rec, meta, models = moe_case()
+    lat, traj, picks = T.sample_loop_two_experts(models, meta["boundary"], meta["guides"], torch.from_numpy(rec["latents0"]),
+                                                 torch.from_numpy(rec["context"]), torch.from_numpy(rec["context_null"]), meta["heads"],
+                                                 meta["layers"], meta["steps"], meta["shift"], y=torch.from_numpy(rec["y"]))
+    assert picks == meta["picks"] and 0 in picks and 1 in picks
+    for i, got in enumerate(traj):
+        assert (got - torch.from_numpy(rec[f"latents_{i + 1}"])).abs().max().item() <= 5e-4
+
+
+def test_product_expert_switch_rule():
+    import lightx2v_amd as L
+
+    class FakeModel:
+        def __init__(self):
+            self.calls = 0
+
+        def set_scheduler(self, s):
+            self.s = s
+
+        def infer(self, inputs):
+            self.calls += 1
+
+    cfg = {"infer_steps": 6, "sample_shift": 5.0, "sample_guide_scale": [3.5, 3.0], "dim": 256, "num_heads": 2, "run_device": "cpu"}
+    sch = L.WanScheduler(cfg)
+    sch.prepare(0, (16, 2, 4, 4), latents=torch.zeros(16, 2, 4, 4))
+    hi, lo = FakeModel(), FakeModel()
+    mm = L.MultiModelStruct([hi, lo], cfg, boundary=0.6)
+    mm.set_scheduler(sch)
+    picks, guides = [], []
+    for i in range(6):
+        sch.step_index = i
+        mm.infer(None)
+        picks.append(mm.cur_model_index)
+        guides.append(sch.sample_guide_scale)
+    ref = T.UniPC(6, 5.0)
+    assert picks == [0 if float(ref.timesteps[i]) >= 600 else 1 for i in range(6)]
+    assert guides == [[3.5, 3.0][p] for p in picks] and hi.calls + lo.calls == 6
 
 
 @pytest.mark.parametrize("name", STEP_CASES)
