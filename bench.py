@@ -116,27 +116,30 @@ def build_model(cfg, device, seed):
 
 
 class AttnTimer:
-    """Wraps the self-attention plugin's apply with events recorded on the stream it launches on."""
+    """Wraps the self-attention plugin's apply with events recorded on the stream it launches on, and
+    sums the algorithmic FLOPs of what was launched (under Ulysses a block's heads arrive in chunks)."""
 
     def __init__(self, plugin):
         self.plugin = plugin
         self.inner = plugin.apply
         self.events = []
+        self.flops = 0.0
         self.enabled = False
         plugin.apply = self.apply
 
-    def apply(self, *a, **kw):
+    def apply(self, q, k, v, *a, **kw):
         if not self.enabled:
-            return self.inner(*a, **kw)
+            return self.inner(q, k, v, *a, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream())
-        out = self.inner(*a, **kw)
+        out = self.inner(q, k, v, *a, **kw)
         e1.record(torch.cuda.current_stream())
         self.events.append((e0, e1))
+        self.flops += 4.0 * q.shape[-3] * k.shape[-3] * q.shape[-2] * q.shape[-1]
         return out
 
-    def mean_ms(self):
-        return sum(a.elapsed_time(b) for a, b in self.events) / max(1, len(self.events))
+    def total_ms(self):
+        return sum(a.elapsed_time(b) for a, b in self.events)
 
 
 def cpu_baseline(D, H, F, full_S, layers, threads):
@@ -294,8 +297,9 @@ def main():
     assert torch.isfinite(noise_pred).all()
     s_per_step = elapsed / args.steps
 
-    attn_ms = sum(t.mean_ms() for t in timers) / len(timers)
-    attn_flops = 4.0 * S_pad * S_pad * (H // seq_p) * (D // H)  # per launch on this rank
+    n_launches = sum(len(t.events) for t in timers)
+    attn_ms = sum(t.total_ms() for t in timers) / max(1, n_launches)          # mean launch duration on this rank
+    attn_flops = sum(t.flops for t in timers) / max(1, n_launches)            # mean algorithmic FLOPs per launch
     achieved = attn_flops / (attn_ms * 1e-3) / 1e12
     sa, ca, ge = block_flops(S, D, H, F)
     step_flops = (sa + ca + ge) * layers * 2
@@ -312,8 +316,8 @@ def main():
             "step_tflops": step_flops / 1e12,
             "achieved_tflops_per_gpu": step_flops / s_per_step / 1e12 / world,
             "roofline": {"kernel": "attn_fwd_w4_kernel<false> (self-attention)", "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": measured_traffic(S_pad, H // seq_p),
-                         "launch_ms": attn_ms, "flops_per_launch": attn_flops, "launches_timed": sum(len(t.events) for t in timers)},
+                         "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": measured_traffic(S_pad, H // seq_p) if n_launches == layers * 2 * args.steps // cfg_p else None,
+                         "launch_ms": attn_ms, "flops_per_launch": attn_flops, "launches_timed": n_launches},
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
