@@ -176,6 +176,8 @@ def main():
     ap.add_argument("--res", default=os.environ.get("LX2V_BENCH_RES", "720p"), choices=sorted(GRIDS))
     ap.add_argument("--layout", default=None, help="cfg_p x seq_p, e.g. 2x4 (default: 1x1, 2x1, 2x2, 2x4 for 1/2/4/8 GPUs)")
     ap.add_argument("--layers", type=int, default=None, help="override the layer count (debug only; the JSON line then says so)")
+    ap.add_argument("--linear", default="bf16", choices=["bf16", "fp8"],
+                    help="arithmetic of the blocks' Linears: bf16 (the headline configuration) or W8A8 e4m3 (the reference's fp8 schemes); attention stays bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -243,6 +245,7 @@ def main():
     cfg = {"num_layers": layers, "num_heads": H, "dim": D, "ffn_dim": F, "task": "t2v", "model_cls": "wan2.1",
            "in_dim": LATENT_CHANNELS, "out_dim": LATENT_CHANNELS, "freq_dim": 256, "infer_steps": 50, "sample_shift": 5.0,
            "sample_guide_scale": GUIDE_SCALE, "enable_cfg": True, "run_device": "cuda",
+           "dit_quant_scheme": "hip-bf16" if args.linear == "bf16" else "hip-fp8",
            "cfg_parallel": cfg_p > 1, "cfg_p_group": cfg_group,
            "seq_parallel": seq_p > 1, "seq_p_group": seq_group, "parallel": {"seq_p_size": seq_p, "cfg_p_size": cfg_p, "seq_p_attn_type": "hip_ulysses"}}
     model = build_model(cfg, dev, seed=1234)  # same seed on every rank: weights are replicated
@@ -306,10 +309,10 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "s/denoise-step Wan2.1-T2V-14B 720p81f" if (args.model, args.res) == ("wan2.1-t2v-14b", "720p") else f"s/denoise-step {args.model} {args.res}81f",
+            "metric": "s/denoise-step Wan2.1-T2V-14B 720p81f" if (args.model, args.res, args.linear) == ("wan2.1-t2v-14b", "720p", "bf16") else f"s/denoise-step {args.model} {args.res}81f" + ("" if args.linear == "bf16" else " (fp8 Linears)"),
             "value": s_per_step, "unit": "s/denoise-step", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": s_per_step * 1e3, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic latents and text features, random-init weights of the named architecture"
+            "dtype": "bf16" if args.linear == "bf16" else "fp8 Linears (W8A8 e4m3) + bf16 attention", "data": "synthetic latents and text features, random-init weights of the named architecture"
                     + ("" if (backend == "nccl" and not share_gpu) else f" [REHEARSAL: backend={backend} share_gpu={share_gpu}, not a measurement]"),
             "config": {"workload": f"{args.model} {args.res} x81f: {S} tokens, full denoise step (pre-infer, {layers} blocks + head, unpatchify) x 2 CFG forwards + CFG combine + UniPC update, text len {TEXT_LEN}",
                        "parallelism": f"cfg_p{cfg_p} x seq_p{seq_p} (ulysses)", "tokens": S, "dim": D, "heads": H, "ffn_dim": F, "layers": layers},

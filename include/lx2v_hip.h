@@ -151,6 +151,26 @@ int lx2v_lincomb_f32(float* out, int64_t n, int terms, const float* const* x, co
 int lx2v_cfg_combine_f32(float* out, const float* cond, const float* uncond, float guide_scale,
                          int64_t n, void* stream);
 
+/* ==== fp8 (OCP e4m3) W8A8 Linear on the CDNA4 fp8 MFMA ===================================== */
+
+/* ---- row-wise dynamic quantisation: scale[r] = max|x[r,:]| / 448 ; out[r,:] = e4m3(x[r,:] / scale[r]) ----
+ * (round to nearest even, saturating).  Per-token for activations, per-output-channel for weights.
+ * Replaces act_quant_fp8_perchannel_sym_sgl (sgl_per_token_quant_fp8) / _vllm (scaled_fp8_quant,
+ * use_per_token_if_dynamic)  lightx2v/common/ops/mm/mm_weight.py:492-501, and the per-channel
+ * FloatQuantizer("e4m3") weight path  mm_weight.py:312-320, lightx2v/utils/quant_utils.py:132-161. */
+int lx2v_quant_fp8_rowwise(const uint16_t* x, int64_t ldx, uint8_t* out, int64_t ldo, float* scale,
+                           int64_t rows, int dim, void* stream);
+
+/* ---- C[M,N] = epilogue((A8 @ W8^T) * a_scale[m] * w_scale[n] + bias), bf16 out ---------------
+ * A8 [M,K] and W8 [N,K] are e4m3 bytes (W in the checkpoint's [out,in] layout), a_scale fp32 [M],
+ * w_scale fp32 [N]; epilogues as lx2v_gemm_bf16.  K % 128 == 0, N % 8 == 0, fp8 row strides % 16.
+ * Replaces MMWeightWfp8channelAfp8channeldynamicSgl.apply ("fp8-sgl": sgl_kernel.fp8_scaled_mm)
+ * and its vllm / q8f siblings  lightx2v/common/ops/mm/mm_weight.py:572-605,806-834,901-928. */
+int lx2v_gemm_fp8(const uint8_t* A, int64_t lda, const float* a_scale, const uint8_t* W, int64_t ldw,
+                  const float* w_scale, const float* bias, uint16_t* C, int64_t ldc, int64_t M,
+                  int64_t N, int64_t K, int epilogue, const uint16_t* resid, int64_t ldr,
+                  const float* gate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

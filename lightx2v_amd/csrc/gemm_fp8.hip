@@ -1,0 +1,237 @@
+// fp8 (OCP e4m3) W8A8 Linear on the CDNA4 block-scaled MFMA for gfx950:
+//   C[M,N] = epilogue((A8[M,K] @ W8[N,K]^T) * a_scale[m] * w_scale[n] + bias)
+// with a per-token (row of A) and a per-output-channel (row of W) fp32 scale, bf16 output.
+//
+// Same structure as the bf16 GEMM (256 x 256 tile, 8 waves as 2 x 4, LDS-DMA staging, the same
+// 128-byte-row LDS image and swizzle); a K-tile is 128 fp8 values = the same 128 bytes per row, and
+// one v_mfma_scale_f32_16x16x128_f8f6f4 (unit scales) covers its whole depth: half as many MFMAs
+// per byte staged, each at twice the bf16 rate.  A lane's operand is 32 consecutive K bytes
+// (k-block lane/16), i.e. two adjacent 16-byte chunks of the swizzled row.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 128;  // BK in fp8 elements = bytes
+constexpr int NTHREADS = 512;
+constexpr int TILE_BYTES = BM * BK;  // 32 KiB, same for A and W
+constexpr int GROUP_M = 8;               // tile rasterisation: 8 row-panels share one column sweep
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+struct GemmParams {
+  const uint8_t* A;
+  const uint8_t* W;
+  const float* a_scale;
+  const float* w_scale;
+  const float* bias;
+  uint16_t* C;
+  const uint16_t* resid;
+  const float* gate;
+  int64_t lda, ldw, ldc, ldr;
+  int M, N, K;
+  int tiles_m, tiles_n;
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+LX2V_DEVICE void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)l, 16, 0, 0);
+}
+
+// Bijective remap so that blocks sharing an XCD (same blockIdx % 8) get a contiguous run of tiles.
+LX2V_DEVICE int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(NTHREADS) void gemm_fp8_kernel(const GemmParams p) {
+  __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];  // [stage][A|W][32 KiB]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 2, wn = wid & 3;
+
+  // ---- tile coordinates (XCD-aware, grouped along M) ----
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int t = xcd_remap(blockIdx.x, nwg);
+  const int group_sz = GROUP_M * p.tiles_n;
+  const int g = t / group_sz;
+  const int first_m = g * GROUP_M;
+  const int gm = min(p.tiles_m - first_m, GROUP_M);
+  const int in_g = t - g * group_sz;
+  const int tile_m = first_m + in_g % gm;
+  const int tile_n = in_g / gm;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- per-thread staging sources: 4 DMA instructions per operand per K-tile ----
+  // LDS byte offset o = i*8192 + tid*16 -> row = o >> 7, physical chunk = (o >> 4) & 7.
+  const uint8_t* a_src[4];
+  const uint8_t* w_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int o = i * 8192 + tid * 16;
+    const int row = o >> 7;
+    const int chunk = ((o >> 4) & 7) ^ ((row >> 1) & 7);
+    const int ar = min(m0 + row, p.M - 1);
+    const int wr = min(n0 + row, p.N - 1);
+    a_src[i] = p.A + (int64_t)ar * p.lda + chunk * 16;
+    w_src[i] = p.W + (int64_t)wr * p.ldw + chunk * 16;
+  }
+  auto stage = [&](int s, int kt) {
+    char* la = lds + s * 2 * TILE_BYTES + wid * 1024;
+    char* lw = la + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(a_src[i] + (int64_t)kt * BK, la + i * 8192);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(w_src[i] + (int64_t)kt * BK, lw + i * 8192);
+  };
+
+  // ---- fragment read offsets ----
+  // A operand of the MFMA = W fragment: row n = wn*64 + nt*16 + (lane & 15), K bytes 32*(lane >> 4) .. +31
+  // B operand of the MFMA = A fragment: row m = wm*128 + mt*16 + (lane & 15)
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_rd[2], w_rd[2];  // byte offsets of the two 16-byte chunks at mt/nt = 0 (rows step by 16 -> +2048 B, swizzle unchanged)
+  {
+    const int arow = wm * 128 + fr, wrow = wn * 64 + fr;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      a_rd[c] = arow * 128 + (((2 * fq + c) ^ ((arow >> 1) & 7)) << 4);
+      w_rd[c] = wrow * 128 + (((2 * fq + c) ^ ((wrow >> 1) & 7)) << 4);
+    }
+  }
+  auto frag = [&](const char* base, const int (&rd)[2], int t) __attribute__((always_inline)) -> i32x8 {
+    const u32x4 lo = *reinterpret_cast<const u32x4*>(base + rd[0] + t * 2048);
+    const u32x4 hi = *reinterpret_cast<const u32x4*>(base + rd[1] + t * 2048);
+    return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+  };
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* la = lds + cur * 2 * TILE_BYTES;
+    const char* lw = la + TILE_BYTES;
+    i32x8 wf[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) wf[nt] = frag(lw, w_rd, nt);
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh) {  // two halves of the wave's 8 row blocks: 64 fragment registers live at a time
+      i32x8 af[4];
+#pragma unroll
+      for (int m4 = 0; m4 < 4; ++m4) af[m4] = frag(la, a_rd, mh * 4 + m4);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int m4 = 0; m4 < 4; ++m4)
+          acc[nt][mh * 4 + m4] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[nt], af[m4], acc[nt][mh * 4 + m4], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue: fp32 math on accumulators -> per-wave LDS image (bf16) -> row stores ----
+  // acc[nt][mt][j] = C'[m = wm*128 + mt*16 + fr][n = wn*64 + nt*16 + fq*4 + j]
+  char* stg = lds + wid * 16384;  // 128 rows x 128 B per wave
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int ncol = n0 + wn * 64 + nt * 16 + fq * 4;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f}, gv = {1.f, 1.f, 1.f, 1.f}, sw = {0.f, 0.f, 0.f, 0.f};
+    if (ncol < p.N) {
+      sw = *reinterpret_cast<const f32x4*>(p.w_scale + ncol);
+      if (p.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(p.bias + ncol);
+      if (EPI == LX2V_EPI_RESIDUAL && p.gate != nullptr) gv = *reinterpret_cast<const f32x4*>(p.gate + ncol);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      float v[4];
+      const float sa = p.a_scale[min(m0 + wm * 128 + mt * 16 + fr, p.M - 1)];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = acc[nt][mt][j] * sa * sw[j] + bv[j];
+        if (EPI == LX2V_EPI_GELU_TANH) v[j] = gelu_tanh(v[j]);
+        if (EPI == LX2V_EPI_RESIDUAL) v[j] *= gv[j];
+      }
+      const int r = mt * 16 + fr;                 // row inside the wave's 128-row image
+      const int slot = nt * 4 + fq;               // 8-byte slot inside the 128-B row
+      const int off = r * 128 + ((((slot >> 1) ^ (r & 7)) << 4) | ((slot & 1) << 3));
+      u32x2 pk = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+      *reinterpret_cast<u32x2*>(stg + off) = pk;
+    }
+  }
+  // Each wave reads back only its own image: a wave-level wait on the LDS writes is enough.
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  const int c8 = lane & 7;  // 16-B chunk inside the 128-B row segment
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int r = it * 8 + (lane >> 3);
+    const int gm_ = m0 + wm * 128 + r;
+    const int gn = n0 + wn * 64 + c8 * 8;
+    u32x4 val = *reinterpret_cast<const u32x4*>(stg + r * 128 + ((c8 ^ (r & 7)) << 4));
+    if (gm_ < p.M && gn < p.N) {
+      if (EPI == LX2V_EPI_RESIDUAL) {
+        float a[8], b[8];
+        unpack8(val, a);
+        unpack8(*reinterpret_cast<const u32x4*>(p.resid + (int64_t)gm_ * p.ldr + gn), b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += b[j];
+        val = pack8(a);
+      }
+      *reinterpret_cast<u32x4*>(p.C + (int64_t)gm_ * p.ldc + gn) = val;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int lx2v_gemm_fp8(const uint8_t* A, int64_t lda, const float* a_scale, const uint8_t* W, int64_t ldw, const float* w_scale,
+                             const float* bias, uint16_t* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
+                             const uint16_t* resid, int64_t ldr, const float* gate, void* stream) {
+  LX2V_REQUIRE(A && W && C && a_scale && w_scale, LX2V_EINVAL, "gemm_fp8: null tensor");
+  LX2V_REQUIRE(M >= 0 && N > 0 && K > 0, LX2V_EINVAL, "gemm_fp8: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
+  LX2V_REQUIRE(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), LX2V_EUNSUP, "gemm_fp8: dimensions must fit in 31 bits");
+  LX2V_REQUIRE(K % BK == 0, LX2V_EUNSUP, "gemm_fp8: K=%lld must be a multiple of %d", (long long)K, BK);
+  LX2V_REQUIRE(N % 8 == 0, LX2V_EUNSUP, "gemm_fp8: N=%lld must be a multiple of 8", (long long)N);
+  LX2V_REQUIRE(lda % 16 == 0 && ldw % 16 == 0 && ldc % 8 == 0, LX2V_EINVAL, "gemm_fp8: fp8 row strides must be multiples of 16, ldc of 8");
+  LX2V_REQUIRE(lda >= K && ldw >= K && ldc >= N, LX2V_EINVAL, "gemm_fp8: row stride smaller than the row length");
+  LX2V_REQUIRE(lx2v_aligned16(A) && lx2v_aligned16(W) && lx2v_aligned16(C) && lx2v_aligned16(w_scale), LX2V_EINVAL, "gemm_fp8: tensors must be 16-byte aligned");
+  LX2V_REQUIRE(bias == nullptr || lx2v_aligned16(bias), LX2V_EINVAL, "gemm_fp8: bias must be 16-byte aligned");
+  LX2V_REQUIRE(epilogue == LX2V_EPI_NONE || epilogue == LX2V_EPI_GELU_TANH || epilogue == LX2V_EPI_RESIDUAL, LX2V_EINVAL, "gemm_fp8: unknown epilogue %d", epilogue);
+  if (epilogue == LX2V_EPI_RESIDUAL) {
+    LX2V_REQUIRE(resid != nullptr && ldr % 8 == 0 && ldr >= N && lx2v_aligned16(resid), LX2V_EINVAL, "gemm_fp8: residual epilogue needs an aligned resid with ldr >= N");
+    LX2V_REQUIRE(gate == nullptr || lx2v_aligned16(gate), LX2V_EINVAL, "gemm_fp8: gate must be 16-byte aligned");
+  }
+  if (M == 0) return LX2V_OK;
+
+  GemmParams p;
+  p.A = A; p.W = W; p.a_scale = a_scale; p.w_scale = w_scale; p.bias = bias; p.C = C; p.resid = resid; p.gate = gate;
+  p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  p.tiles_m = (int)((M + BM - 1) / BM);
+  p.tiles_n = (int)((N + BN - 1) / BN);
+  const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
+  LX2V_REQUIRE(nwg < (1LL << 31), LX2V_EUNSUP, "gemm_fp8: too many tiles");
+  const dim3 grid((unsigned)nwg), block(NTHREADS);
+  hipStream_t st = (hipStream_t)stream;
+  switch (epilogue) {
+    case LX2V_EPI_NONE: hipLaunchKernelGGL(gemm_fp8_kernel<LX2V_EPI_NONE>, grid, block, 0, st, p); break;
+    case LX2V_EPI_GELU_TANH: hipLaunchKernelGGL(gemm_fp8_kernel<LX2V_EPI_GELU_TANH>, grid, block, 0, st, p); break;
+    default: hipLaunchKernelGGL(gemm_fp8_kernel<LX2V_EPI_RESIDUAL>, grid, block, 0, st, p); break;
+  }
+  LX2V_CHECK_LAUNCH("gemm_fp8");
+  return LX2V_OK;
+}

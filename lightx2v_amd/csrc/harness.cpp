@@ -188,6 +188,28 @@ static void bench_gemm(int M, int N, int K, int epi, int iters) {
   hipFree(a); hipFree(w); hipFree(c); hipFree(bias); hipFree(gate);
 }
 
+static void bench_gemm_fp8(int M, int N, int K, int epi, int iters) {
+  uint16_t* a = dev_normal((size_t)M * K, 4, 1.0f);
+  uint16_t* w = dev_normal((size_t)N * K, 5, 0.02f);
+  uint8_t *a8, *w8;
+  float *as, *ws, *bias;
+  uint16_t* c;
+  HIPCHK(hipMalloc(&a8, (size_t)M * K));
+  HIPCHK(hipMalloc(&w8, (size_t)N * K));
+  HIPCHK(hipMalloc(&as, (size_t)M * 4));
+  HIPCHK(hipMalloc(&ws, (size_t)N * 4));
+  HIPCHK(hipMalloc(&bias, (size_t)N * 4));
+  HIPCHK(hipMemset(bias, 0, (size_t)N * 4));
+  HIPCHK(hipMalloc(&c, (size_t)M * N * 2));
+  LXCHK(lx2v_quant_fp8_rowwise(w, K, w8, K, ws, N, K, nullptr));
+  const float qms = time_ms([&] { LXCHK(lx2v_quant_fp8_rowwise(a, K, a8, K, as, M, K, nullptr)); }, iters);
+  printf("quant_fp8 rows=%d dim=%d : %.3f ms  %.0f GB/s\n", M, K, qms, 3.0 * M * K / qms * 1e-6);
+  const float ms = time_ms([&] { LXCHK(lx2v_gemm_fp8(a8, K, as, w8, K, ws, bias, c, N, M, N, K, epi, epi == 2 ? c : nullptr, N, nullptr, nullptr)); }, iters);
+  const double flops = 2.0 * M * (double)N * K;
+  printf("gemm_fp8 M=%d N=%d K=%d epi=%d : %.3f ms  %.1f TFLOP/s (%.1f%% of 5000)\n", M, N, K, epi, ms, flops / ms * 1e-9, flops / ms * 1e-9 / 50.0);
+  hipFree(a); hipFree(w); hipFree(a8); hipFree(w8); hipFree(as); hipFree(ws); hipFree(bias); hipFree(c);
+}
+
 static void bench_ew(int S, int D, int iters) {
   uint16_t* x = dev_normal((size_t)S * D, 6, 1.0f);
   uint16_t* y = dev_normal((size_t)S * D, 7, 1.0f);
@@ -233,6 +255,12 @@ int main(int argc, char** argv) {
     bench_gemm(S, F, D, 1, iters);
     bench_gemm(S, D, F, 2, iters);
     bench_gemm(512, 2 * D, D, 0, iters);
+  }
+  if (!strcmp(what, "gemm8") || !strcmp(what, "all")) {
+    bench_gemm_fp8(S, 3 * D, D, 0, iters);
+    bench_gemm_fp8(S, D, D, 2, iters);
+    bench_gemm_fp8(S, F, D, 1, iters);
+    bench_gemm_fp8(S, D, F, 2, iters);
   }
   if (!strcmp(what, "ew") || !strcmp(what, "all")) bench_ew(S, D, iters);
   return 0;

@@ -103,6 +103,41 @@ __global__ __launch_bounds__(256) void cfg_combine_kernel(float* out, const floa
   }
 }
 
+// Row-wise symmetric fp8 (OCP e4m3) quantisation: scale[r] = max|x[r,:]| / 448, out = x / scale.
+// Built with IEEE division (this file is compiled without fast-math): the scale and its reciprocal
+// are the correctly rounded quotients a host computes.  One row per wave; two sweeps over the row (absmax, then convert), the second one served by L2 --
+// rows can be wider than the register-resident row kernels allow (FFN inner dim).
+__global__ __launch_bounds__(256) void quant_fp8_rowwise_kernel(const uint16_t* __restrict__ x, int64_t ldx, uint8_t* __restrict__ out, int64_t ldo,
+                                                                float* __restrict__ scale, int64_t rows, int dim) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const uint16_t* xr = x + row * ldx;
+  const int nchunks = dim >> 3;
+  float amax = 0.f;
+  for (int ch = lane; ch < nchunks; ch += 64) {
+    float f[8];
+    unpack8(*reinterpret_cast<const u32x4*>(xr + (int64_t)ch * 8), f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(f[i]));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+  const float sc = __fdiv_rn(fmaxf(amax, 1e-12f), 448.0f);
+  const float inv = __frcp_rn(sc);
+  if (lane == 0) scale[row] = sc;
+  uint8_t* orow = out + row * ldo;
+  for (int ch = lane; ch < nchunks; ch += 64) {
+    float f[8];
+    unpack8(*reinterpret_cast<const u32x4*>(xr + (int64_t)ch * 8), f);
+    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, 0, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, lo, true);
+    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * inv, f[5] * inv, 0, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] * inv, f[7] * inv, hi, true);
+    *reinterpret_cast<u32x2*>(orow + (int64_t)ch * 8) = u32x2{(uint32_t)lo, (uint32_t)hi};
+  }
+}
+
 }  // namespace
 
 extern "C" int lx2v_patchify_bf16(float* latents, uint16_t* out, int64_t ldo, int channels, int frames, int height, int width, int round_latents, void* stream) {
@@ -172,5 +207,17 @@ extern "C" int lx2v_cfg_combine_f32(float* out, const float* cond, const float* 
   if (n == 0) return LX2V_OK;
   hipLaunchKernelGGL(cfg_combine_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, out, cond, uncond, guide_scale, n / 4);
   LX2V_CHECK_LAUNCH("cfg_combine");
+  return LX2V_OK;
+}
+
+extern "C" int lx2v_quant_fp8_rowwise(const uint16_t* x, int64_t ldx, uint8_t* out, int64_t ldo, float* scale, int64_t rows, int dim, void* stream) {
+  LX2V_REQUIRE(x && out && scale, LX2V_EINVAL, "quant_fp8: null tensor");
+  LX2V_REQUIRE(rows >= 0 && dim > 0 && dim % 8 == 0, LX2V_EINVAL, "quant_fp8: dim=%d must be a positive multiple of 8", dim);
+  LX2V_REQUIRE(ldx % 8 == 0 && ldo % 8 == 0 && ldx >= dim && ldo >= dim, LX2V_EINVAL, "quant_fp8: row strides must be multiples of 8 and >= dim");
+  LX2V_REQUIRE(lx2v_aligned16(x) && (reinterpret_cast<uintptr_t>(out) & 7u) == 0, LX2V_EINVAL, "quant_fp8: x must be 16-byte, out 8-byte aligned");
+  if (rows == 0) return LX2V_OK;
+  hipLaunchKernelGGL(quant_fp8_rowwise_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo, scale,
+                     rows, dim);
+  LX2V_CHECK_LAUNCH("quant_fp8");
   return LX2V_OK;
 }

@@ -35,6 +35,8 @@ _SIGNATURES = {
     "lx2v_silu_bf16": [_P, _P, _I64, _P],
     "lx2v_lincomb_f32": [_P, _I64, _I, _P, _P, _P],
     "lx2v_cfg_combine_f32": [_P, _P, _P, _F, _I64, _P],
+    "lx2v_quant_fp8_rowwise": [_P, _I64, _P, _I64, _P, _I64, _I, _P],
+    "lx2v_gemm_fp8": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _P, _I64, _P, _P],
 }
 EXPORTS = tuple(_SIGNATURES) + ("lx2v_abi_version", "lx2v_last_error")
 
@@ -292,4 +294,39 @@ def cfg_combine(cond: torch.Tensor, uncond: torch.Tensor, guide_scale: float) ->
         raise Lx2vError("cfg_combine: shapes differ")
     out = torch.empty_like(cond)
     _check(load().lx2v_cfg_combine_f32(out.data_ptr(), cond.data_ptr(), uncond.data_ptr(), float(guide_scale), cond.numel(), _stream()), "lx2v_cfg_combine_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------- fp8 W8A8
+def quant_fp8_rowwise(x: torch.Tensor):
+    """bf16 [rows, dim] -> (e4m3 [rows, dim] as torch.float8_e4m3fn, fp32 scale [rows]); x ~= q * scale."""
+    _need_bf16_cuda("quant_fp8.x", x)
+    rows, dim = x.shape
+    q = torch.empty((rows, dim), dtype=torch.float8_e4m3fn, device=x.device)
+    scale = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    _check(load().lx2v_quant_fp8_rowwise(x.data_ptr(), x.stride(0), q.data_ptr(), q.stride(0), scale.data_ptr(), rows, dim, _stream()), "lx2v_quant_fp8_rowwise")
+    return q, scale
+
+
+def gemm_fp8(a8: torch.Tensor, a_scale: torch.Tensor, w8: torch.Tensor, w_scale: torch.Tensor, bias=None, epilogue: int = EPI_NONE,
+             resid: Optional[torch.Tensor] = None, gate=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(a8 [M,K] e4m3) @ (w8 [N,K] e4m3)^T scaled per row / per output channel -> bf16 [M,N]."""
+    for n, t in (("a8", a8), ("w8", w8)):
+        if not t.is_cuda or t.dtype != torch.float8_e4m3fn or t.stride(-1) != 1:
+            raise Lx2vError(f"gemm_fp8: {n} must be a GPU float8_e4m3fn tensor with a contiguous inner dimension")
+    M, K = a8.shape
+    N = w8.shape[0]
+    if w8.shape[1] != K:
+        raise Lx2vError(f"gemm_fp8: K mismatch {K} vs {w8.shape[1]}")
+    a_scale = _vec_f32("gemm_fp8.a_scale", a_scale, M, a8)
+    w_scale = _vec_f32("gemm_fp8.w_scale", w_scale, N, a8)
+    bias = _vec_f32("gemm_fp8.bias", bias, N, a8)
+    gate = _vec_f32("gemm_fp8.gate", gate, N, a8)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=a8.device)
+    if epilogue == EPI_RESIDUAL:
+        _need_bf16_cuda("gemm_fp8.resid", resid)
+    st = load().lx2v_gemm_fp8(a8.data_ptr(), a8.stride(0), a_scale.data_ptr(), w8.data_ptr(), w8.stride(0), w_scale.data_ptr(), _ptr(bias),
+                              out.data_ptr(), out.stride(0), M, N, K, epilogue, _ptr(resid), 0 if resid is None else resid.stride(0), _ptr(gate), _stream())
+    _check(st, "lx2v_gemm_fp8")
     return out

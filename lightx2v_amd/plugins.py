@@ -123,10 +123,28 @@ class HipMMWeight:
     def set_config(self, config={}):
         self.config = config
 
+    supports_kseg = True  # apply_residual_ can read a K-segmented A operand
+
     def adopt(self, weight_nk: torch.Tensor, bias: Optional[torch.Tensor]):
         """Use existing storage (e.g. a slice of a fused q|k|v weight) instead of copying."""
         self.weight_nk = weight_nk
         self.bias = bias
+
+    @classmethod
+    def fused(cls, mods):
+        """One plugin whose weight is the row-wise concatenation of `mods`' weights (q|k|v, k|v):
+        one GEMM instead of several.  The members are re-pointed at slices of the fused storage so
+        their separate copies are released."""
+        out = cls(None, None)
+        w = torch.cat([m.weight_nk for m in mods], dim=0).contiguous()
+        b = torch.cat([m.bias for m in mods], dim=0).contiguous()
+        out.adopt(w, b)
+        o = 0
+        for m in mods:
+            n = m.weight_nk.shape[0]
+            m.adopt(w[o:o + n], b[o:o + n])
+            o += n
+        return out
 
     def load(self, weight_dict):
         w = weight_dict[self.weight_name]
@@ -185,6 +203,91 @@ class HipMMWeight:
         """resid <- resid + (x W^T + b) * gate, in place; returns resid."""
         return hip.gemm(input_tensor, self.weight_nk, self.bias, epilogue=hip.EPI_RESIDUAL, resid=resid, gate=gate, out=resid,
                         a_kseg=a_kseg, a_kseg_stride=a_kseg_stride)
+
+
+@MM_WEIGHT_REGISTER("hip-fp8")
+class HipFp8MMWeight(HipMMWeight):
+    """W8A8 in OCP e4m3 on the CDNA4 fp8 MFMA: per-output-channel weight scale, dynamic per-token
+    activation scale, bf16 output -- the semantics of the reference's "fp8-sgl" / "fp8-vllm" /
+    "fp8-q8f" schemes (lightx2v/common/ops/mm/mm_weight.py:572-605,806-834,901-928).  Loads either
+    a pre-quantised checkpoint (`<name>.weight` in float8_e4m3fn + `<name>.weight_scale`, the
+    reference's `load_quantized`, :269-290) or, like its `weight_auto_quant`, quantises a bf16/fp32
+    weight at load time."""
+
+    def __init__(self, weight_name, bias_name, create_cuda_buffer=False, lazy_load=False, lazy_load_file=None, is_post_adapter=False):
+        super().__init__(weight_name, bias_name, create_cuda_buffer, lazy_load, lazy_load_file, is_post_adapter)
+        self.weight_scale_name = None if weight_name is None else weight_name.removesuffix(".weight") + ".weight_scale"
+        self.weight_scale: Optional[torch.Tensor] = None  # [N] fp32
+
+    def load(self, weight_dict):
+        w = weight_dict[self.weight_name]
+        b = weight_dict[self.bias_name] if self.bias_name is not None else None
+        self.bias = _device_ready(b, torch.float32)
+        if w.dtype == torch.float8_e4m3fn:
+            self.weight_nk = w.contiguous()
+            self.weight_scale = weight_dict[self.weight_scale_name].to(torch.float32).reshape(-1).contiguous()
+        else:
+            if not w.is_cuda:
+                if not torch.cuda.is_available():
+                    raise RuntimeError("hip-fp8: quantising a weight at load time runs on the GPU; no GPU is visible (no CPU fallback exists)")
+                w = w.cuda()
+            self.weight_nk, self.weight_scale = hip.quant_fp8_rowwise(w.to(COMPUTE_DTYPE).contiguous())
+
+    def _calculate_size(self):
+        return super()._calculate_size() + self.weight_scale.numel() * 4
+
+    def to_cuda(self, non_blocking=False):
+        super().to_cuda(non_blocking)
+        self.weight_scale = self.weight_scale.cuda(non_blocking=non_blocking)
+
+    def to_cpu(self, non_blocking=False):
+        super().to_cpu(non_blocking)
+        self.weight_scale = self.weight_scale.to("cpu", non_blocking=non_blocking)
+
+    def state_dict(self, destination=None):
+        destination = super().state_dict(destination)
+        destination[self.weight_scale_name] = self.weight_scale
+        return destination
+
+    def load_state_dict(self, destination, block_index, adapter_block_index=None):
+        raise NotImplementedError("hip-fp8: block-streamed (offload) loading is not built")
+
+    supports_kseg = False  # the activation is re-quantised row by row, which needs whole rows
+
+    def adopt(self, weight_nk, bias, weight_scale=None):
+        if weight_scale is None:
+            raise ValueError("hip-fp8: adopting storage needs the per-channel weight scale with it")
+        self.weight_nk, self.bias, self.weight_scale = weight_nk, bias, weight_scale
+
+    @classmethod
+    def fused(cls, mods):
+        out = cls(None, None)
+        w = torch.cat([m.weight_nk for m in mods], dim=0).contiguous()
+        b = torch.cat([m.bias for m in mods], dim=0).contiguous()
+        sc = torch.cat([m.weight_scale for m in mods], dim=0).contiguous()
+        out.adopt(w, b, sc)
+        o = 0
+        for m in mods:
+            n = m.weight_nk.shape[0]
+            m.adopt(w[o:o + n], b[o:o + n], sc[o:o + n])
+            o += n
+        return out
+
+    def _run(self, x, epilogue, resid=None, gate=None):
+        xq, xs = hip.quant_fp8_rowwise(x)
+        return hip.gemm_fp8(xq, xs, self.weight_nk, self.weight_scale, self.bias, epilogue=epilogue, resid=resid, gate=gate,
+                            out=resid if epilogue == hip.EPI_RESIDUAL else None)
+
+    def apply(self, input_tensor):
+        return self._run(input_tensor, hip.EPI_NONE)
+
+    def apply_gelu(self, input_tensor):
+        return self._run(input_tensor, hip.EPI_GELU_TANH)
+
+    def apply_residual_(self, input_tensor, resid, gate=None, a_kseg=0, a_kseg_stride=0):
+        if a_kseg != 0:
+            raise NotImplementedError("hip-fp8: K-segmented operands are built for the bf16 scheme only")
+        return self._run(input_tensor, hip.EPI_RESIDUAL, resid=resid, gate=gate)
 
 
 # ----------------------------------------------------------------------------------- norms

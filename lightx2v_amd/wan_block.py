@@ -69,19 +69,13 @@ class WanSelfAttention(WeightModule):
         self.add_module("self_attn_1", ATTN_WEIGHT_REGISTER[config["self_attn_1_type"]]())
         if config["seq_parallel"]:
             self.add_module("self_attn_1_parallel", ATTN_WEIGHT_REGISTER[config.get("parallel", {}).get("seq_p_attn_type", "hip_ulysses")]())
-        self._qkv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+        self._qkv = None
 
-    def fused_qkv(self) -> Tuple[torch.Tensor, torch.Tensor]:
-        """[3D, D] weight and [3D] bias for one q|k|v GEMM.  Built once; the q/k/v plugins are then
-        re-pointed at slices of it so the separate copies are released."""
+    def fused_qkv(self):
+        """One Linear with the [3D, D] q|k|v weight (one GEMM instead of three).  Built once; the
+        q/k/v plugins are then re-pointed at slices of it so the separate copies are released."""
         if self._qkv is None:
-            mods = [self.self_attn_q, self.self_attn_k, self.self_attn_v]
-            w = torch.cat([m.weight_nk for m in mods], dim=0).contiguous()
-            b = torch.cat([m.bias for m in mods], dim=0).contiguous()
-            d = mods[0].weight_nk.shape[0]
-            for i, m in enumerate(mods):
-                m.adopt(w[i * d:(i + 1) * d], b[i * d:(i + 1) * d])
-            self._qkv = (w, b)
+            self._qkv = type(self.self_attn_q).fused([self.self_attn_q, self.self_attn_k, self.self_attn_v])
         return self._qkv
 
 
@@ -103,17 +97,11 @@ class WanCrossAttention(WeightModule):
             self.add_module("cross_attn_v_img", mm(f"{p}.cross_attn.v_img.weight", f"{p}.cross_attn.v_img.bias", *extra))
             self.add_module("cross_attn_norm_k_img", rms(f"{p}.cross_attn.norm_k_img.weight", *extra))
             self.add_module("cross_attn_2", ATTN_WEIGHT_REGISTER[config["cross_attn_2_type"]]())
-        self._kv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+        self._kv = None
 
-    def fused_kv(self) -> Tuple[torch.Tensor, torch.Tensor]:
+    def fused_kv(self):
         if self._kv is None:
-            mods = [self.cross_attn_k, self.cross_attn_v]
-            w = torch.cat([m.weight_nk for m in mods], dim=0).contiguous()
-            b = torch.cat([m.bias for m in mods], dim=0).contiguous()
-            d = mods[0].weight_nk.shape[0]
-            for i, m in enumerate(mods):
-                m.adopt(w[i * d:(i + 1) * d], b[i * d:(i + 1) * d])
-            self._kv = (w, b)
+            self._kv = type(self.cross_attn_k).fused([self.cross_attn_k, self.cross_attn_v])
         return self._kv
 
 
@@ -153,7 +141,8 @@ class WanTransformerWeights(WeightModule):
         self.blocks = WeightModuleList([WanTransformerAttentionBlock(i, self.task, self.mm_type, config) for i in range(self.blocks_num)])
         self.add_module("blocks", self.blocks)
         self.register_parameter("norm", LN_WEIGHT_REGISTER[config["ln_type"]]())
-        self.add_module("head", MM_WEIGHT_REGISTER[self.mm_type]("head.head.weight", "head.head.bias"))
+        # the head stays unquantised whatever the block scheme (weights/transformer_weights.py:32)
+        self.add_module("head", MM_WEIGHT_REGISTER["hip-bf16"]("head.head.weight", "head.head.bias"))
         self.register_parameter("head_modulation", TENSOR_REGISTER["Default"]("head.modulation"))
 
 
@@ -254,8 +243,7 @@ class WanTransformerInfer:
         rope_in_attn = self.rope_type == "hip_attn"
         if self.fused_block:
             norm1_out = phase.norm1.apply_modulate(x, scale_msa, shift_msa)
-            w, b = phase.fused_qkv()
-            qkv = hip.gemm(norm1_out, w, b)  # [S, 3D]
+            qkv = phase.fused_qkv().apply(norm1_out)  # [S, 3D]
             q2, k2, v2 = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
             table = None if rope_in_attn else self.cos_sin
             phase.self_attn_norm_q.apply_rope_(q2, table, d)
@@ -274,7 +262,7 @@ class WanTransformerInfer:
         if self.config["seq_parallel"]:
             par = phase.self_attn_1_parallel
             cu = torch.tensor([0, S], dtype=torch.int32)
-            if self.fused_block and hasattr(par, "apply_segmented"):
+            if self.fused_block and hasattr(par, "apply_segmented") and phase.self_attn_o.supports_kseg:
                 # the all-to-all result stays in its [source rank][S/N][H/N*d] receive layout; the
                 # output projection reads it as a K-segmented A operand (no gather copy)
                 recv, kseg, kseg_stride = par.apply_segmented(q, k, v, attention_module=phase.self_attn_1, seq_p_group=self.seq_p_group)
@@ -306,8 +294,7 @@ class WanTransformerInfer:
             norm3_out = phase.norm3.apply(x)
             q2 = phase.cross_attn_q.apply(norm3_out)
             phase.cross_attn_norm_q.apply_(q2)
-            w, b = phase.fused_kv()
-            kv = hip.gemm(context, w, b)  # [T, 2D]
+            kv = phase.fused_kv().apply(context)  # [T, 2D]
             k2, v2 = kv[:, :D], kv[:, D:]
             phase.cross_attn_norm_k.apply_(k2)
             q, k, v = q2.view(S, H, d), k2.unflatten(1, (H, d)), v2.unflatten(1, (H, d))

@@ -315,3 +315,30 @@ def cosine(a: torch.Tensor, b: torch.Tensor) -> float:
     a = a.double().flatten()
     b = b.double().flatten()
     return float((a @ b) / (a.norm() * b.norm() + 1e-300))
+
+
+# --------------------------------------------------------------------------- fp8 W8A8 Linear
+FP8_MAX = 448.0  # largest finite OCP e4m3 value
+
+
+def quant_fp8_rowwise(x: torch.Tensor):
+    """Dynamic symmetric e4m3 quantisation with one scale per row: scale = max|row| / 448,
+    q = e4m3(row * (1/scale)) (round to nearest even).  Per token for activations
+    (`sgl_per_token_quant_fp8` / vllm `scaled_fp8_quant(use_per_token_if_dynamic=True)`,
+    lightx2v/common/ops/mm/mm_weight.py:492-501), per output channel for weights
+    (`FloatQuantizer("e4m3", True, "per_channel")`, mm_weight.py:312-320,
+    lightx2v/utils/quant_utils.py:132-161).  Those kernels live in wheels that are absent here
+    (sgl-kernel 0.1.8, vllm 0.9.2) and the reference holds no fixture for them: parity unpinned --
+    this is their published formula.  Returns (q as float8_e4m3fn, scale fp32 [rows])."""
+    x = x.float()
+    scale = x.abs().amax(dim=1).clamp_min(1e-12) / FP8_MAX
+    inv = 1.0 / scale
+    return (x * inv[:, None]).to(torch.float8_e4m3fn), scale
+
+
+def linear_fp8(x: torch.Tensor, w_q: torch.Tensor, w_scale: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`fp8-sgl` apply (mm_weight.py:901-928): quantise x per token, multiply in the quantised
+    domain, rescale by both scales, add the bias."""
+    x_q, x_scale = quant_fp8_rowwise(x)
+    y = (x_q.float() @ w_q.float().t()) * x_scale[:, None] * w_scale[None, :]
+    return y if b is None else y + b

@@ -1,0 +1,90 @@
+"""GPU: fp8 (OCP e4m3) W8A8 Linear -- row-wise quantisation kernel and the fp8-MFMA GEMM -- against
+the restated formula of the reference's "fp8-sgl" scheme (oracle.wan_block_ref.quant_fp8_rowwise /
+linear_fp8; parity unpinned: the reference's kernels for it live in absent wheels)."""
+import pytest
+import torch
+
+import lightx2v_amd as L
+from lightx2v_amd import hip
+from oracle import wan_block_ref as R
+from tests.util import case_inputs, cos, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, scale=1.0):
+    return (torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("rows,dim", [(1, 128), (7, 256), (130, 1536), (33, 5120), (5, 13824), (9, 520)])
+def test_quant_fp8_rowwise_bit_exact(cuda, rows, dim):
+    x = _rand((rows, dim), 70 + rows)
+    x[0, :3] = torch.tensor([448.0, -1000.0, 3.0e-3])  # a row whose maximum is far above the rest
+    if rows > 2:
+        x[2] = 0  # all-zero row: scale floor, zeros out
+    q_ref, s_ref = R.quant_fp8_rowwise(x)
+    q, s = hip.quant_fp8_rowwise(x.to(cuda))
+    assert torch.equal(s.cpu(), s_ref)
+    assert torch.equal(q.cpu().view(torch.uint8), q_ref.view(torch.uint8))
+
+
+@pytest.mark.parametrize("M,N,K", [(16, 64, 128), (300, 512, 256), (1000, 1536, 1536), (257, 264, 384), (64, 5120, 13824)])
+def test_gemm_fp8_matches_quantised_domain_product(cuda, M, N, K):
+    a, w = _rand((M, K), 80), _rand((N, K), 81, 0.05)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(82)) * 0.1
+    aq, a_s = R.quant_fp8_rowwise(a)
+    wq, w_s = R.quant_fp8_rowwise(w)
+    ref = (aq.double() @ wq.double().t()) * a_s.double()[:, None] * w_s.double()[None, :] + bias.double()
+    out = hip.gemm_fp8(aq.to(cuda), a_s.to(cuda), wq.to(cuda), w_s.to(cuda), bias.to(cuda))
+    # products of e4m3 values are exact in fp32; what separates the two is the fp32 accumulation
+    # order and the final bf16 rounding
+    tol = 2.0 ** -8 * ref.abs().max().item() + 1e-3
+    assert (out.double().cpu() - ref).abs().max().item() <= tol
+    # and the whole scheme (quantise + multiply) stays close to the unquantised product
+    assert cos(out, R.linear(a.float(), w.float(), bias)) >= 0.999
+
+
+def test_gemm_fp8_epilogues_and_plugin(cuda):
+    M, N, K = 300, 512, 256
+    a, w = _rand((M, K), 90), _rand((N, K), 91, 0.05)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(92)) * 0.1
+    gate = torch.randn(N, generator=torch.Generator().manual_seed(93))
+    resid = _rand((M, N), 94)
+    mm = L.MM_WEIGHT_REGISTER["hip-fp8"]("w.weight", "w.bias")
+    mm.load({"w.weight": w.to(cuda), "w.bias": bias.to(cuda)})
+    wq, w_s = R.quant_fp8_rowwise(w)
+    assert torch.equal(mm.weight_nk.cpu().view(torch.uint8), wq.view(torch.uint8)) and torch.equal(mm.weight_scale.cpu(), w_s)
+    ref = R.linear_fp8(a, wq, w_s, bias)
+    assert (mm.apply(a.to(cuda)).float().cpu() - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item() + 1e-3
+    g = torch.nn.functional.gelu(ref, approximate="tanh")
+    assert (mm.apply_gelu(a.to(cuda)).float().cpu() - g).abs().max().item() <= 2.0 ** -7 * g.abs().max().item() + 1e-3
+    r = resid.to(cuda).clone()
+    mm.apply_residual_(a.to(cuda), r, gate=gate.to(cuda))
+    rr = resid.float() + ref * gate
+    assert (r.float().cpu() - rr).abs().max().item() <= 2.0 ** -7 * rr.abs().max().item() + 1e-3
+    # a pre-quantised checkpoint loads as is
+    mm2 = L.MM_WEIGHT_REGISTER["hip-fp8"]("w.weight", "w.bias")
+    mm2.load({"w.weight": wq.to(cuda), "w.weight_scale": w_s.to(cuda), "w.bias": bias.to(cuda)})
+    assert torch.equal(mm2.apply(a.to(cuda)), mm.apply(a.to(cuda)))
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_block_with_fp8_linears(cuda, fused):
+    """The whole block with every Linear in W8A8 fp8 (both runners) against the fp32 oracle."""
+    rec = load_golden("wan1p3b_g3x6x8")
+    c = case_inputs(rec)
+    cfg = {"num_layers": 1, "num_heads": c["heads"], "dim": c["dim"], "task": "t2v", "dit_quant_scheme": "hip-fp8", "fused_block": fused}
+    W = L.WanTransformerWeights(cfg)
+    wd = {k: v.to(cuda) for k, v in {**c["w"], **c["hw"]}.items()}
+    W.load(wd)
+    W.to_cuda()
+    inf = L.WanTransformerInfer(cfg)
+    inf.cos_sin = R.cos_sin_to_real(c["cos_sin"]).contiguous().to(cuda)
+    pre = L.WanPreInferModuleOutput(embed=c["embed"].to(cuda), grid_sizes=c["grid"], x=c["x"].to(torch.bfloat16).to(cuda),
+                                    embed0=c["embed0"].to(cuda), context=c["context"].to(torch.bfloat16).to(cuda))
+    inf.get_scheduler_values = lambda: None
+    out = inf.infer_main_blocks(W.blocks, pre)
+    ref = R.block_forward(c["x"], c["embed0"], c["context"], c["w"], c["cos_sin"], c["heads"])
+    c_out, c_delta = cos(out, ref), cos(out.float().cpu() - c["x"], ref - c["x"])
+    print(f"\nfp8 block: output cosine {c_out:.6f}, delta cosine {c_delta:.6f}")
+    assert c_out >= 0.999 and c_delta >= 0.99

@@ -135,7 +135,8 @@ def test_weight_tree_names_and_load_roundtrip():
     assert "blocks.0.compute_phases.0.self_attn_q" in names and "head_modulation" in names
     assert W.calculate_size() > 0
     # fused q|k|v aliases the same storage as the per-projection plugins afterwards
-    w, b = sa.fused_qkv()
+    fq = sa.fused_qkv()
+    w, b = fq.weight_nk, fq.bias
     assert w.shape == (768, 256) and sa.self_attn_k.weight_nk.data_ptr() == w[256:512].data_ptr()
     assert torch.equal(sa.self_attn_v.bias, b[512:])
 
