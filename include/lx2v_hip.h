@@ -47,11 +47,17 @@ int lx2v_ln_modulate_bf16(const uint16_t* x, int64_t ldx, const float* ln_w, con
  * i: (y[2i], y[2i+1]) *= (cos[r,i] + j sin[r,i]).  rope_cos_sin is fp32 [rows, head_dim]
  * laid out cos(head_dim/2) || sin(head_dim/2) per row (the reference's flashinfer layout,
  * lightx2v/models/schedulers/wan/scheduler.py:90-95), or NULL for no rotation.
- * `w` may be NULL (rotation only; then no normalisation either when `do_norm` == 0).
- * In-place allowed (out == x).
+ * `do_norm`: 0 = no normalisation (rotation only), 1 = statistics over the whole row with
+ * w[dim] (Wan: all heads jointly), 2 = statistics per head with w[head_dim] shared by every head
+ * (HunyuanVideo-1.5: the norm is applied to the [L, H, d] view; head_dim a power of two 8..512).
+ * `w` may be NULL (no weight).  In-place allowed (out == x).
  * Replaces RMSWeightSgl.apply  lightx2v/common/ops/norm/rms_norm_weight.py:131-146
+ * (called on [S, D] at wan/infer/transformer_infer.py:164-165 and on [L, H, d] at
+ * hunyuan_video/infer/transformer_infer.py:171-172, 204-205)
  * and apply_wan_rope_with_torch / _flashinfer
- *                              lightx2v/models/networks/wan/infer/utils.py:12-28,64-87. */
+ *                              lightx2v/models/networks/wan/infer/utils.py:12-28,64-87,
+ * apply_hunyuan_rope_with_torch / _flashinfer
+ *                              lightx2v/models/networks/hunyuan_video/infer/transformer_infer.py:41-95. */
 int lx2v_rmsnorm_rope_bf16(const uint16_t* x, int64_t ldx, const float* w, int do_norm,
                            const float* rope_cos_sin, int head_dim, uint16_t* out, int64_t ldo,
                            int64_t rows, int dim, float eps, void* stream);

@@ -1,4 +1,4 @@
-"""lightx2v_amd: the Wan DiT transformer-block forward as gfx950 (MI355X) HIP kernels behind
+"""lightx2v_amd: the Wan DiT (and HunyuanVideo-1.5 double-stream) transformer-block forward as gfx950 (MI355X) HIP kernels behind
 LightX2V's plugin surface (attention / matmul / norm registries + a WanTransformerInfer-shaped
 runner).  Importing the package registers the plugins; the shared library is loaded on first use.
 """
@@ -18,6 +18,12 @@ from .wan_block import (  # noqa: F401,E402
     WanTransformerAttentionBlock,
     WanTransformerInfer,
     WanTransformerWeights,
+)
+from .hy_block import (  # noqa: F401,E402
+    HunyuanVideo15InferModuleOutput,
+    HunyuanVideo15TransformerInfer,
+    HunyuanVideo15TransformerWeights,
+    MMDoubleStreamBlock,
 )
 from .rope_table import build_rope_table, shard_rope_table  # noqa: F401,E402
 from .wan_model import (  # noqa: F401,E402

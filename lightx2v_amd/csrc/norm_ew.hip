@@ -90,6 +90,10 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(
 }
 
 // y = x * rsqrt(mean(x^2)+eps) * w, then optional per-head interleaved-pair rotation.
+// do_norm: 0 = no normalisation, 1 = statistics over the whole row with a [dim] weight,
+// 2 = statistics per head (head_dim a power of two, 8..512) with a [head_dim] weight shared by
+// every head: a head's head_dim/8 chunks sit in adjacent lanes of one register slot, so its sum is a
+// butterfly over that lane group.
 template <int NC>
 __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(
     const uint16_t* __restrict__ x, int64_t ldx, const float* __restrict__ w, int do_norm,
@@ -101,14 +105,28 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(
   const int nchunks = dim >> 3;
   RowRegs<NC> r;
   load_row<NC>(x + row * ldx, nchunks, lane, r);
-  float rstd = 1.0f;
-  if (do_norm) {
+  float rstd[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) rstd[c] = 1.0f;
+  if (do_norm == 1) {
     float ss = 0.f;
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
       for (int i = 0; i < 8; ++i) ss += r.f[c][i] * r.f[c][i];
-    rstd = rsqrtf(wave_sum(ss) / (float)dim + eps);
+    const float rs = rsqrtf(wave_sum(ss) / (float)dim + eps);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) rstd[c] = rs;
+  } else if (do_norm == 2) {
+    const int lanes_per_head = head_dim >> 3;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ss += r.f[c][i] * r.f[c][i];
+      for (int off = lanes_per_head >> 1; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+      rstd[c] = rsqrtf(ss / (float)head_dim + eps);
+    }
   }
   const int half = head_dim >> 1;
   const float* cs_row = cos_sin != nullptr ? cos_sin + row * head_dim : nullptr;
@@ -119,9 +137,10 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(
     const int col = ch * 8;
     float y[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) y[i] = r.f[c][i] * rstd;
+    for (int i = 0; i < 8; ++i) y[i] = r.f[c][i] * rstd[c];
     if (w != nullptr) {
-      const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + col), w1 = *reinterpret_cast<const f32x4*>(w + col + 4);
+      const int wcol = do_norm == 2 ? col % head_dim : col;
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + wcol), w1 = *reinterpret_cast<const f32x4*>(w + wcol + 4);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         y[i] *= w0[i];
@@ -262,6 +281,10 @@ extern "C" int lx2v_rmsnorm_rope_bf16(const uint16_t* x, int64_t ldx, const floa
                  "rmsnorm_rope: head_dim=%d must be a multiple of 8 dividing dim=%d", head_dim, dim);
     LX2V_REQUIRE(lx2v_aligned16(rope_cos_sin), LX2V_EINVAL, "rmsnorm_rope: rope table must be 16-byte aligned");
   }
+  LX2V_REQUIRE(do_norm >= 0 && do_norm <= 2, LX2V_EINVAL, "rmsnorm_rope: do_norm=%d (0 none, 1 whole row, 2 per head)", do_norm);
+  if (do_norm == 2)
+    LX2V_REQUIRE(head_dim >= 8 && head_dim <= 512 && (head_dim & (head_dim - 1)) == 0 && dim % head_dim == 0, LX2V_EUNSUP,
+                 "rmsnorm_rope: per-head statistics need head_dim=%d to be a power of two in [8, 512] dividing dim=%d", head_dim, dim);
   if (rows == 0) return LX2V_OK;
   const dim3 grid((unsigned)((rows + kRowsPerBlock - 1) / kRowsPerBlock)), block(256);
   hipStream_t st = (hipStream_t)stream;

@@ -125,14 +125,17 @@ def ln_modulate(x: torch.Tensor, ln_w=None, ln_b=None, scale=None, shift=None, e
 
 
 def rmsnorm_rope(x: torch.Tensor, weight=None, rope_cos_sin: Optional[torch.Tensor] = None, head_dim: int = 128,
-                 eps: float = 1e-6, out: Optional[torch.Tensor] = None, do_norm: bool = True) -> torch.Tensor:
-    """x [rows, dim] (row stride free). rope_cos_sin fp32 [rows, head_dim] (cos || sin) or None."""
+                 eps: float = 1e-6, out: Optional[torch.Tensor] = None, do_norm: bool = True, per_head: bool = False) -> torch.Tensor:
+    """x [rows, dim] (row stride free). rope_cos_sin fp32 [rows, head_dim] (cos || sin) or None.
+    `per_head`: statistics over each head's `head_dim` columns with a [head_dim] weight shared by
+    all heads, instead of over the whole row with a [dim] weight."""
     _need_bf16_cuda("rmsnorm_rope.x", x)
     assert x.dim() == 2
     rows, dim = x.shape
     if out is None:
         out = torch.empty((rows, dim), dtype=x.dtype, device=x.device)
-    w = _vec_f32("rms weight", weight, dim, x)
+    w = _vec_f32("rms weight", weight, head_dim if per_head else dim, x)
+    do_norm = 2 if (do_norm and per_head) else int(bool(do_norm))
     if rope_cos_sin is not None:
         if rope_cos_sin.dtype != torch.float32 or not rope_cos_sin.is_contiguous() or tuple(rope_cos_sin.shape) != (rows, head_dim):
             raise Lx2vError(f"rope table must be contiguous fp32 [{rows}, {head_dim}], got {tuple(rope_cos_sin.shape)} {rope_cos_sin.dtype}")

@@ -193,8 +193,10 @@ class HipMMWeight:
             self.bias = None
 
     # -- compute
-    def apply(self, input_tensor):
-        return hip.gemm(input_tensor, self.weight_nk, self.bias)
+    def apply(self, input_tensor, out=None):
+        """`out`: optional preallocated [M, N] destination (row stride free), e.g. a row range of a
+        larger buffer; the reference signature has no such slot and allocates."""
+        return hip.gemm(input_tensor, self.weight_nk, self.bias, out=out)
 
     def apply_gelu(self, input_tensor):
         return hip.gemm(input_tensor, self.weight_nk, self.bias, epilogue=hip.EPI_GELU_TANH)
@@ -273,13 +275,13 @@ class HipFp8MMWeight(HipMMWeight):
             o += n
         return out
 
-    def _run(self, x, epilogue, resid=None, gate=None):
+    def _run(self, x, epilogue, resid=None, gate=None, out=None):
         xq, xs = hip.quant_fp8_rowwise(x)
         return hip.gemm_fp8(xq, xs, self.weight_nk, self.weight_scale, self.bias, epilogue=epilogue, resid=resid, gate=gate,
-                            out=resid if epilogue == hip.EPI_RESIDUAL else None)
+                            out=resid if epilogue == hip.EPI_RESIDUAL else out)
 
-    def apply(self, input_tensor):
-        return self._run(input_tensor, hip.EPI_NONE)
+    def apply(self, input_tensor, out=None):
+        return self._run(input_tensor, hip.EPI_NONE, out=out)
 
     def apply_gelu(self, input_tensor):
         return self._run(input_tensor, hip.EPI_GELU_TANH)
@@ -405,6 +407,12 @@ class HipRMSWeight(_NormBase):
 
     def apply_(self, x2d):
         return hip.rmsnorm_rope(x2d, self.weight, None, eps=self.eps, out=x2d)
+
+    def apply_per_head_rope_(self, x2d, rope_cos_sin, head_dim):
+        """In place on [rows, H*head_dim]: RMSNorm of every head separately with this plugin's
+        [head_dim] weight (the result of `apply` on the [rows, H, head_dim] view), then the
+        interleaved RoPE when a table is given."""
+        return hip.rmsnorm_rope(x2d, self.weight, rope_cos_sin, head_dim=head_dim, eps=self.eps, out=x2d, per_head=True)
 
 
 # ----------------------------------------------------------------------------------- tensors

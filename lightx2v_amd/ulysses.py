@@ -47,12 +47,18 @@ class HipUlyssesAttnWeight(_AttnBase):
         self.chunks = max(1, int(os.environ.get("LX2V_ULYSSES_CHUNKS", "2")))
 
     # ---- exchange core -------------------------------------------------------------------------
-    def _exchange_attend(self, q, k, v, attention_module, group, model_cls=None) -> Tuple[torch.Tensor, int, int, int]:
-        """Returns (back, segments, sl, seg): `back` is [segments][sl][seg] with the segments in
-        global head order, i.e. the logical [sl, H*d] output has columns [g*seg, (g+1)*seg) at back[g]."""
+    def _exchange_attend(self, q, k, v, attention_module, group, model_cls=None, txt=None) -> Tuple[torch.Tensor, int, int, int, Optional[torch.Tensor]]:
+        """Returns (back, segments, sl, seg, txt_out): `back` is [segments][sl][seg] with the segments in
+        global head order, i.e. the logical [sl, H*d] output has columns [g*seg, (g+1)*seg) at back[g].
+
+        `txt` = (tq, tk, tv), each [Lt, H, d] and identical on every rank (HunyuanVideo layout,
+        ulysses_attn.py:80-88,105-116): the text rows are appended after the gathered image rows of
+        every head group this rank attends, and their outputs are gathered along the head axis into
+        `txt_out` [Lt, H*d] (None without a text part)."""
         if q.dim() == 4:
             q, k, v = (t.reshape(-1, t.shape[-2], t.shape[-1]) for t in (q, k, v))
         world = dist.get_world_size(group)
+        rank = dist.get_rank(group)
         sl, heads, d = q.shape
         if heads % world != 0:
             raise ValueError(f"hip_ulysses: num_heads={heads} is not divisible by the sequence-parallel size {world}")
@@ -60,42 +66,62 @@ class HipUlyssesAttnWeight(_AttnBase):
         chunks = max(c for c in range(1, self.chunks + 1) if hs % c == 0)
         hc = hs // chunks
         dim = heads * d
+        lt = 0 if txt is None else txt[0].shape[0]
         # Head group g = heads [g*hc, (g+1)*hc) goes to rank g % world as its chunk g // world, so the
         # pack kernel's natural order [g][sl][q|k|v][hc*d] is already [chunk][dest rank][...]: every
         # chunk is one contiguous all-to-all, and the returned segments come back in head order.
         send = self._pack(q.reshape(sl, dim), k.reshape(sl, dim), v.reshape(sl, dim), world * chunks).view(chunks, world, sl, 3, hc * d)
-        recv = torch.empty_like(send)
-        arrivals = [dist.all_to_all_single(recv[c], send[c], group=group, async_op=True) for c in range(chunks)]
+        recv = torch.empty((chunks, world * sl + lt, 3, hc * d), dtype=send.dtype, device=send.device)  # image rows of all ranks, then text rows
+        arrivals = [dist.all_to_all_single(recv[c, :world * sl].view(world, sl, 3, hc * d), send[c], group=group, async_op=True) for c in range(chunks)]
+        if lt:
+            for c in range(chunks):
+                g = c * world + rank
+                for i, t in enumerate(txt):
+                    recv[c, world * sl:, i] = t[:, g * hc:(g + 1) * hc].reshape(lt, hc * d)
         back = torch.empty((chunks, world, sl, hc * d), dtype=send.dtype, device=send.device)  # [chunk][src rank][sl][hc*d]
+        txt_g = torch.empty((chunks, world, lt, hc * d), dtype=send.dtype, device=send.device) if lt else None
         returns, keep = [], []
         for c in range(chunks):
             # chunk c+1.. are still in flight while chunk c is attended; its output leaves while chunk c+1 is attended
             arrivals[c].wait()
-            r = recv[c].view(world * sl, 3, hc, d)
+            r = recv[c].view(world * sl + lt, 3, hc, d)
             attn = attention_module.apply(q=r[:, 0], k=r[:, 1], v=r[:, 2], cu_seqlens_q=None, cu_seqlens_kv=None,
-                                          max_seqlen_q=world * sl, max_seqlen_kv=world * sl, model_cls=model_cls)  # [S, hc*d]
+                                          max_seqlen_q=world * sl + lt, max_seqlen_kv=world * sl + lt, model_cls=model_cls)  # [S (+Lt), hc*d]
             attn = attn.contiguous()
             keep.append(attn)
-            returns.append(dist.all_to_all_single(back[c], attn.view(world, sl, hc * d), group=group, async_op=True))
+            returns.append(dist.all_to_all_single(back[c], attn[:world * sl].view(world, sl, hc * d), group=group, async_op=True))
+            if lt:
+                returns.append(dist.all_gather(list(txt_g[c].unbind(0)), attn[world * sl:], group=group, async_op=True))
         for w in returns:
             w.wait()
-        return back, world * chunks, sl, hc * d
+        txt_out = txt_g.permute(2, 0, 1, 3).reshape(lt, dim) if lt else None  # group g = c*world + r -> columns [g*hc*d, ...)
+        return back, world * chunks, sl, hc * d, txt_out
 
     # ---- reference-compatible entry ------------------------------------------------------------
     def apply(self, q, k, v, img_qkv_len, cu_seqlens_qkv, attention_module=None, seq_p_group=None, model_cls=None, use_fp8_comm=False):
-        """q,k,v [S/N, H, d] -> [S/N, H*d] (ulysses_attn.py:16)."""
+        """q,k,v [S/N (+ Lt), H, d] -> [S/N (+ Lt), H*d] (ulysses_attn.py:16): the first `img_qkv_len`
+        rows are this rank's shard of the image tokens, rows after them (up to cu_seqlens_qkv[1]) are
+        text tokens replicated on every rank."""
         if use_fp8_comm:
             raise NotImplementedError("hip_ulysses: fp8 payload exchange is not built yet")
-        if int(cu_seqlens_qkv[-1]) != int(img_qkv_len) or q.shape[0] != img_qkv_len:
-            raise NotImplementedError("hip_ulysses: a text part after the image tokens (HunyuanVideo layout) is not built yet")
-        back, nseg, sl, seg = self._exchange_attend(q, k, v, attention_module, seq_p_group, model_cls)
-        return back.view(nseg, sl, seg).permute(1, 0, 2).reshape(sl, nseg * seg)
+        if len(cu_seqlens_qkv) != 2:
+            raise NotImplementedError("hip_ulysses: a masked text tail (three-entry cu_seqlens_qkv) is not built")
+        if q.dim() == 4:
+            q, k, v = (t.reshape(-1, t.shape[-2], t.shape[-1]) for t in (q, k, v))
+        img_qkv_len = int(img_qkv_len)
+        total = int(cu_seqlens_qkv[-1])
+        if q.shape[0] != total or total < img_qkv_len:
+            raise ValueError(f"hip_ulysses: q has {q.shape[0]} rows, cu_seqlens_qkv says {total}, image part {img_qkv_len}")
+        txt = None if total == img_qkv_len else tuple(t[img_qkv_len:] for t in (q, k, v))
+        back, nseg, sl, seg, txt_out = self._exchange_attend(q[:img_qkv_len], k[:img_qkv_len], v[:img_qkv_len], attention_module, seq_p_group, model_cls, txt)
+        img_out = back.view(nseg, sl, seg).permute(1, 0, 2).reshape(sl, nseg * seg)
+        return img_out if txt_out is None else torch.cat([img_out, txt_out])
 
     # ---- zero-copy form for the fused block runner ---------------------------------------------
     def apply_segmented(self, q, k, v, attention_module=None, seq_p_group=None, model_cls=None):
         """Returns (buffer, a_kseg, a_kseg_stride): logical [S/N, H*d] matrix whose K columns
         [g*seg, (g+1)*seg) live at buffer + g*a_kseg_stride + row*seg."""
-        back, nseg, sl, seg = self._exchange_attend(q, k, v, attention_module, seq_p_group, model_cls)
+        back, nseg, sl, seg, _ = self._exchange_attend(q, k, v, attention_module, seq_p_group, model_cls)
         return back.view(nseg * sl, seg)[:sl], seg, sl * seg
 
 

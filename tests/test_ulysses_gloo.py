@@ -83,3 +83,39 @@ def test_ulysses_and_cfg_groups_gloo(tmp_path, cfg_p, seq_p):
         res = torch.load(os.path.join(str(tmp_path), f"r{r}.pt"))
         assert res["err"] < 1e-5 and res["err2"] < 1e-5, res
         assert res["raised"] and res["ok_cfg"], res
+
+
+def _txt_worker(rank, world, port, golden_path, out_dir):
+    import numpy as np
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lightx2v_amd import ulysses
+
+    rec = np.load(golden_path)
+    li, lt, H, d, seed = (int(rec[k]) for k in ("li", "lt", "H", "d", "seed"))
+    g = torch.Generator().manual_seed(seed)
+    q, k, v = (torch.randn(li + lt, H, d, generator=g) for _ in range(3))
+    sl = li // world
+    ql, kl, vl = (torch.cat([t[rank * sl:(rank + 1) * sl], t[li:]]) for t in (q, k, v))
+    errs = {}
+    for chunks in (1, 2):
+        os.environ["LX2V_ULYSSES_CHUNKS"] = str(chunks)
+        uly = ulysses.HipUlyssesAttnWeight(pack_fn=_torch_pack)
+        out = uly.apply(ql, kl, vl, img_qkv_len=sl, cu_seqlens_qkv=torch.tensor([0, sl + lt], dtype=torch.int32), attention_module=_OracleAttn(), seq_p_group=None)
+        errs[chunks] = (out - torch.from_numpy(rec["out"][rank])).abs().max().item()
+    torch.save(errs, os.path.join(out_dir, f"t{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ulysses_with_replicated_text_rows_matches_reference_run(tmp_path, world):
+    """Image rows sharded, text rows replicated (HunyuanVideo layout): every rank's output equals
+    what the reference's UlyssesAttnWeight produced under gloo (fixture from oracle/gen_golden_hy.py)."""
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"hy_ulysses_txt_n{world}.npz")
+    mp.spawn(_txt_worker, args=(world, _free_port(), golden, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        errs = torch.load(os.path.join(str(tmp_path), f"t{r}.pt"))
+        assert all(e < 1e-5 for e in errs.values()), errs
