@@ -78,3 +78,51 @@ def test_sequence_parallel_block_two_ranks_one_gpu(cuda, tmp_path, fused):
     ref = R.block_forward(xp, c["embed0"], c["context"], c["w"], cs, c["heads"])[:S]
     assert cos(got, ref) >= 0.9999
     assert cos(got - c["x"], ref - c["x"]) >= 0.995
+
+
+def _hy_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import lightx2v_amd as L
+    from lightx2v_amd import ulysses
+    from tests.test_hy_oracle import hy_case_inputs
+    from tests.util import load_golden
+
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    c = hy_case_inputs(load_golden("hy_tiny_d256"))  # 48 image tokens + 19 text tokens, H = 2
+    _, seq_idx, seq_group, _ = ulysses.make_groups(1, world)
+    cfg = {"mm_double_blocks_depth": c["depth"], "heads_num": c["heads"], "hidden_size": c["dim"], "seq_parallel": True, "seq_p_group": seq_group,
+           "parallel": {"seq_p_size": world, "seq_p_attn_type": "hip_ulysses"}}
+    W = L.HunyuanVideo15TransformerWeights(cfg)
+    wd = {}
+    for b in c["blocks"]:
+        wd.update(b)
+    wd.update(c["fw"])
+    W.load({k: v.to(dev) for k, v in wd.items()})
+    inf = L.HunyuanVideo15TransformerInfer(cfg)
+    sl = c["L"] // world
+    rows = slice(seq_idx * sl, (seq_idx + 1) * sl)
+    inf.scheduler.cos_sin = c["cos_sin"][rows].contiguous().to(dev)
+    bf = lambda t: t.to(torch.bfloat16).to(dev)
+    io = L.HunyuanVideo15InferModuleOutput(img=bf(c["img"][:, rows]).contiguous(), txt=bf(c["txt"]), vec=bf(c["vec"]), grid_sizes=c["grid"])
+    out = inf.infer(W, io)  # both blocks + final layer on this rank's image rows
+    torch.cuda.synchronize()
+    torch.save({"final": out.float().cpu(), "txt": io.txt.float().cpu()}, os.path.join(out_dir, f"hy{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_hunyuan_double_blocks_sequence_parallel_two_ranks_one_gpu(cuda, tmp_path):
+    """Image rows sharded over 2 ranks, text rows replicated: the gathered final-layer output
+    equals the reference's unsharded run, and both ranks end with the same text stream."""
+    from tests.util import cos, load_golden
+
+    world = 2
+    mp.spawn(_hy_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), f"hy{r}.pt")) for r in range(world)]
+    rec = load_golden("hy_tiny_d256")
+    got = torch.cat([r["final"][0] for r in res])
+    assert cos(got, torch.from_numpy(rec["final_out"])) >= 0.9995
+    assert cos(res[0]["txt"], res[1]["txt"]) >= 0.99999
