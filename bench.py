@@ -39,6 +39,12 @@ MODELS = {
     "wan2.1-t2v-14b": (5120, 40, 13824, 40),
     "wan2.1-t2v-1.3b": (1536, 12, 8960, 30),
 }
+HY_MODELS = {
+    # name: hidden, heads, mlp, double blocks (HunyuanVideo-1.5 transformer)
+    "hunyuan-1.5": (2048, 16, 8192, 54),
+}
+HY_GRIDS = {"720p": (31, 45, 80), "480p": (21, 30, 53)}  # latent tokens, patch (1,1,1), VAE stride (4,16,16): 121 / 81 frames
+HY_TEXT_LEN = 256  # valid text tokens after the pre-infer's mask crop (synthetic)
 GRIDS = {"720p": (21, 45, 80), "480p": (21, 30, 52)}  # (f, h, w) latent tokens for 81 frames, patch (1,2,2)
 TEXT_LEN = 512
 TEXT_DIM = 4096  # umT5-xxl features
@@ -167,12 +173,125 @@ def cpu_baseline(D, H, F, full_S, layers, threads):
     }
 
 
+def run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu):
+    """HunyuanVideo-1.5 (4-step distilled, no CFG): one step = all double-stream blocks + final layer on
+    synthetic pre-infer outputs (image tokens, text tokens, conditioning vector) + the Euler update.
+    The model's pre-infer (token refiner, byT5 / SigLIP reorder) is outside the built path."""
+    import lightx2v_amd as L
+    from lightx2v_amd import ulysses
+    from lightx2v_amd.rope_table import build_hunyuan_rope_table
+
+    D, H, F, layers = HY_MODELS[args.model]
+    if args.layers is not None:
+        layers = args.layers
+    grid = HY_GRIDS[args.res]
+    S = grid[0] * grid[1] * grid[2]
+    if cfg_p != 1:
+        seq_p, cfg_p = world, 1  # the distilled model runs without CFG: every rank joins the sequence group
+    if H % seq_p != 0:
+        raise SystemExit(f"heads_num={H} not divisible by seq_p={seq_p}")
+    seq_idx, seq_group = 0, None
+    if world > 1:
+        _, seq_idx, seq_group, _ = ulysses.make_groups(1, seq_p)
+    cfg = {"mm_double_blocks_depth": layers, "heads_num": H, "hidden_size": D, "task": "t2v",
+           "dit_quant_scheme": "hip-bf16" if args.linear == "bf16" else "hip-fp8",
+           "seq_parallel": seq_p > 1, "seq_p_group": seq_group, "parallel": {"seq_p_size": seq_p, "seq_p_attn_type": "hip_ulysses"}}
+    W = L.HunyuanVideo15TransformerWeights(cfg)
+    g = torch.Generator(device=dev).manual_seed(1234)  # same seed on every rank: weights are replicated
+
+    def rn(*shape, std=1.0, dtype=torch.bfloat16):
+        return (torch.randn(*shape, generator=g, device=dev, dtype=torch.float32) * std).to(dtype)
+
+    for i in range(layers):
+        p, wd = f"double_blocks.{i}.", {}
+        for br in ("img", "txt"):
+            for name, (o, k) in {"mod.linear": (6 * D, D), "attn_q": (D, D), "attn_k": (D, D), "attn_v": (D, D), "attn_proj": (D, D),
+                                 "mlp.fc1": (F, D), "mlp.fc2": (D, F)}.items():
+                wd[f"{p}{br}_{name}.weight"] = rn(o, k, std=0.02 if name != "mod.linear" else 1.0 / math.sqrt(D))
+                wd[f"{p}{br}_{name}.bias"] = rn(o, std=0.02, dtype=torch.float32)
+            for n in ("q", "k"):
+                wd[f"{p}{br}_attn_{n}_norm.weight"] = torch.ones(D // H, device=dev)
+        W.double_blocks[i].load(wd)
+        W.double_blocks[i].img_branch.fused_qkv()
+        W.double_blocks[i].txt_branch.fused_qkv()
+    W.final_layer.load({"final_layer.adaLN_modulation.1.weight": rn(2 * D, D, std=1.0 / math.sqrt(D)), "final_layer.adaLN_modulation.1.bias": rn(2 * D, std=0.02, dtype=torch.float32),
+                        "final_layer.linear.weight": rn(32, D, std=0.02), "final_layer.linear.bias": rn(32, std=0.02, dtype=torch.float32)})
+    inf = L.HunyuanVideo15TransformerInfer(cfg)
+    S_pad = S + (seq_p - S % seq_p) % seq_p
+    sl = S_pad // seq_p
+    table = torch.zeros(S_pad, D // H)
+    table[:S] = build_hunyuan_rope_table(grid, D // H)
+    inf.scheduler.cos_sin = table[seq_idx * sl:(seq_idx + 1) * sl].contiguous().to(dev)
+    g2 = torch.Generator(device=dev).manual_seed(99)
+    img_tokens = torch.zeros(1, S_pad, D, device=dev, dtype=torch.bfloat16)
+    img_tokens[:, :S] = torch.randn(1, S, D, generator=g2, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    img_local = img_tokens[:, seq_idx * sl:(seq_idx + 1) * sl].contiguous()
+    txt = torch.randn(1, HY_TEXT_LEN, D, generator=g2, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    vec = torch.nn.functional.silu(0.5 * torch.randn(1, D, generator=g2, device=dev, dtype=torch.float32)).to(torch.bfloat16)
+    latents = torch.randn(sl, 32, generator=g2, device=dev, dtype=torch.float32)  # token-major view of this rank's latent rows
+    sigmas = torch.linspace(1.0, 0.0, 5).tolist()
+    timers = [AttnTimer(W.double_blocks[i].self_attention) for i in range(layers)]
+    step_no = [0]
+
+    def step():
+        i = step_no[0] % 4
+        step_no[0] += 1
+        io = L.HunyuanVideo15InferModuleOutput(img=img_local, txt=txt, vec=vec, grid_sizes=grid)
+        pred = inf.infer(W, io)[0].float()  # [sl, 32]
+        latents.add_(pred, alpha=sigmas[i + 1] - sigmas[i])  # Euler update of the flow-matching sampler
+        return latents
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    for t in timers:
+        t.enabled = True
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(out).all()
+    s_per_step = elapsed / args.steps
+    n_launches = sum(len(t.events) for t in timers)
+    attn_ms = sum(t.total_ms() for t in timers) / max(1, n_launches)
+    attn_flops = sum(t.flops for t in timers) / max(1, n_launches)
+    achieved = attn_flops / (attn_ms * 1e-3) / 1e12
+    Sj = S + HY_TEXT_LEN
+    step_flops = (4.0 * Sj * Sj * D + 2.0 * Sj * D * (4 * D + 2 * F)) * layers
+    frames = {31: 121, 21: 81}[grid[0]]
+    return {
+        "metric": f"s/denoise-step {args.model} {args.res}{frames}f" + ("" if args.linear == "bf16" else " (fp8 Linears)"),
+        "value": s_per_step, "unit": "s/denoise-step", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": s_per_step * 1e3, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
+        "dtype": "bf16" if args.linear == "bf16" else "fp8 Linears (W8A8 e4m3) + bf16 attention",
+        "data": "synthetic image/text tokens and conditioning vector, random-init weights of the named architecture"
+                + ("" if (backend == "nccl" and not share_gpu) else f" [REHEARSAL: backend={backend} share_gpu={share_gpu}, not a measurement]"),
+        "config": {"workload": f"{args.model} {args.res} x{frames}f: {S} image + {HY_TEXT_LEN} text tokens, {layers} double-stream blocks + final layer + Euler update, no CFG (distilled schedule); pre-infer not included",
+                   "parallelism": f"seq_p{seq_p} (ulysses)", "tokens": S, "dim": D, "heads": H, "ffn_dim": F, "layers": layers},
+        "step_tflops": step_flops / 1e12, "achieved_tflops_per_gpu": step_flops / s_per_step / 1e12 / world,
+        "roofline": {"kernel": "attn_fwd_w4_kernel<false> (joint image+text attention)", "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                     "launch_ms": attn_ms, "flops_per_launch": attn_flops, "launches_timed": n_launches},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--model", default=os.environ.get("LX2V_BENCH_MODEL", "wan2.1-t2v-14b"), choices=sorted(MODELS))
+    ap.add_argument("--model", default=os.environ.get("LX2V_BENCH_MODEL", "wan2.1-t2v-14b"), choices=sorted(MODELS) + sorted(HY_MODELS))
     ap.add_argument("--res", default=os.environ.get("LX2V_BENCH_RES", "720p"), choices=sorted(GRIDS))
     ap.add_argument("--layout", default=None, help="cfg_p x seq_p, e.g. 2x4 (default: 1x1, 2x1, 2x2, 2x4 for 1/2/4/8 GPUs)")
     ap.add_argument("--layers", type=int, default=None, help="override the layer count (debug only; the JSON line then says so)")
@@ -229,6 +348,15 @@ def main():
 
     import lightx2v_amd as L
     from lightx2v_amd import ulysses
+
+    if args.model in HY_MODELS:
+        line = run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     D, H, F, layers = MODELS[args.model]
     if args.layers is not None:

@@ -49,3 +49,21 @@ def shard_rope_table(table: torch.Tensor, world_size: int, rank: int) -> torch.T
         table = torch.cat([table, table.new_zeros(total - s, table.shape[1])], dim=0)
     per = total // world_size
     return table[rank * per:(rank + 1) * per].contiguous()
+
+
+def build_hunyuan_rope_table(grid: Tuple[int, int, int], head_dim: int = 128, rope_dim_list=(16, 56, 56), theta: float = 256.0, device="cpu") -> torch.Tensor:
+    """HunyuanVideo-1.5's table in the same [tokens, head_dim] = cos || sin layout
+    (lightx2v/models/schedulers/hunyuan_video/scheduler.py:123-142 over
+    posemb_layers.py:169-283): axis `a` owns rope_dim_list[a]/2 slots with angle
+    pos_a * theta^(-2j / rope_dim_list[a]); tokens ordered t-major, then h, then w."""
+    if sum(rope_dim_list) != head_dim:
+        raise ValueError(f"sum(rope_dim_list)={sum(rope_dim_list)} must equal head_dim={head_dim}")
+    parts = []
+    for a, (n, dim) in enumerate(zip(grid, rope_dim_list)):
+        inv = 1.0 / (theta ** (torch.arange(0, dim, 2)[: dim // 2].float() / dim))
+        shape = [1, 1, 1, dim // 2]
+        shape[a] = n
+        ang = torch.outer(torch.arange(n, dtype=torch.float32), inv).view(shape)
+        parts.append(ang.expand(grid[0], grid[1], grid[2], dim // 2))
+    ang = torch.cat(parts, dim=-1).reshape(grid[0] * grid[1] * grid[2], head_dim // 2)
+    return torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1).contiguous().to(device)

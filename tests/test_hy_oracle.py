@@ -82,3 +82,11 @@ def test_container_names_and_roundtrip():
         L.HunyuanVideo15TransformerWeights(dict(cfg, dit_quant_scheme="nope"))
     with pytest.raises(NotImplementedError):
         L.HunyuanVideo15TransformerWeights(dict(cfg, cpu_offload=True))
+
+
+def test_product_rope_table_equals_reference_table():
+    from lightx2v_amd.rope_table import build_hunyuan_rope_table
+
+    rec = load_golden("hy_tiny_d256")
+    assert torch.equal(build_hunyuan_rope_table((2, 4, 6)), torch.from_numpy(rec["cos_sin"]))
+    assert torch.equal(build_hunyuan_rope_table((3, 5, 7)), HY.build_cos_sin((3, 5, 7)))
