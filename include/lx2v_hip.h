@@ -167,6 +167,13 @@ int lx2v_cfg_combine_f32(float* out, const float* cond, const float* uncond, flo
 int lx2v_quant_fp8_rowwise(const uint16_t* x, int64_t ldx, uint8_t* out, int64_t ldo, float* scale,
                            int64_t rows, int dim, void* stream);
 
+/* ---- inverse for the fp8 Ulysses payload: out[r,:] = bf16(e4m3(q[r,:]) * bf16(scale[r])) --------
+ * (the value of `q.to(bf16) * scale.to(bf16)`).  With lx2v_quant_fp8_rowwise on rows of head_dim
+ * values it replaces quant_fp8_vllm / dequant_fp8_vllm  lightx2v/utils/quant_utils.py:180-186 as
+ * used around the all-to-alls at lightx2v/common/ops/attn/ulysses_attn.py:59-73,125-131. */
+int lx2v_dequant_fp8_rowwise(const uint8_t* q, int64_t ldq, const float* scale, uint16_t* out, int64_t ldo,
+                             int64_t rows, int dim, void* stream);
+
 /* ---- C[M,N] = epilogue((A8 @ W8^T) * a_scale[m] * w_scale[n] + bias), bf16 out ---------------
  * A8 [M,K] and W8 [N,K] are e4m3 bytes (W in the checkpoint's [out,in] layout), a_scale fp32 [M],
  * w_scale fp32 [N]; epilogues as lx2v_gemm_bf16.  K % 128 == 0, N % 8 == 0, fp8 row strides % 16.

@@ -105,29 +105,31 @@ __global__ __launch_bounds__(256) void cfg_combine_kernel(float* out, const floa
 
 // Row-wise symmetric fp8 (OCP e4m3) quantisation: scale[r] = max|x[r,:]| / 448, out = x / scale.
 // Built with IEEE division (this file is compiled without fast-math): the scale and its reciprocal
-// are the correctly rounded quotients a host computes.  One row per wave; two sweeps over the row (absmax, then convert), the second one served by L2 --
-// rows can be wider than the register-resident row kernels allow (FFN inner dim).
+// are the correctly rounded quotients a host computes.  A row is handled by `lpr` adjacent lanes
+// (64 = one row per wave; short rows such as one head of 128 values take 16 lanes, four rows per
+// wave); two sweeps over the row (absmax, then convert), the second one served by L2 -- rows can be
+// wider than the register-resident row kernels allow (FFN inner dim).
 __global__ __launch_bounds__(256) void quant_fp8_rowwise_kernel(const uint16_t* __restrict__ x, int64_t ldx, uint8_t* __restrict__ out, int64_t ldo,
-                                                                float* __restrict__ scale, int64_t rows, int dim) {
+                                                                float* __restrict__ scale, int64_t rows, int dim, int lpr) {
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int l = lane & (lpr - 1);
+  const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / lpr) + lane / lpr;
   if (row >= rows) return;
   const uint16_t* xr = x + row * ldx;
   const int nchunks = dim >> 3;
   float amax = 0.f;
-  for (int ch = lane; ch < nchunks; ch += 64) {
+  for (int ch = l; ch < nchunks; ch += lpr) {
     float f[8];
     unpack8(*reinterpret_cast<const u32x4*>(xr + (int64_t)ch * 8), f);
 #pragma unroll
     for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(f[i]));
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+  for (int off = lpr >> 1; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
   const float sc = __fdiv_rn(fmaxf(amax, 1e-12f), 448.0f);
   const float inv = __frcp_rn(sc);
-  if (lane == 0) scale[row] = sc;
+  if (l == 0) scale[row] = sc;
   uint8_t* orow = out + row * ldo;
-  for (int ch = lane; ch < nchunks; ch += 64) {
+  for (int ch = l; ch < nchunks; ch += lpr) {
     float f[8];
     unpack8(*reinterpret_cast<const u32x4*>(xr + (int64_t)ch * 8), f);
     int lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, 0, false);
@@ -135,6 +137,30 @@ __global__ __launch_bounds__(256) void quant_fp8_rowwise_kernel(const uint16_t* 
     int hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * inv, f[5] * inv, 0, false);
     hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] * inv, f[7] * inv, hi, true);
     *reinterpret_cast<u32x2*>(orow + (int64_t)ch * 8) = u32x2{(uint32_t)lo, (uint32_t)hi};
+  }
+}
+
+// out[r, :] = bf16(e4m3(q[r, :]) * bf16(scale[r])): the value a bf16 multiply of the widened
+// byte by the bf16-rounded scale gives (one rounding: the fp32 product of two bf16 values is exact).
+__global__ __launch_bounds__(256) void dequant_fp8_rowwise_kernel(const uint8_t* __restrict__ q, int64_t ldq, const float* __restrict__ scale,
+                                                                  uint16_t* __restrict__ out, int64_t ldo, int64_t rows, int dim) {
+  const int nchunks = dim >> 3;
+  const int64_t total = rows * nchunks;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / nchunks;
+    const int col = (int)(i - row * nchunks) * 8;
+    const u32x2 v = *reinterpret_cast<const u32x2*>(q + row * ldq + col);
+    const float sc = __uint_as_float(pack2(scale[row], 0.f) << 16);
+    float f[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8((int)v[h], false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)v[h], true);
+      f[4 * h] = a[0] * sc;
+      f[4 * h + 1] = a[1] * sc;
+      f[4 * h + 2] = b[0] * sc;
+      f[4 * h + 3] = b[1] * sc;
+    }
+    *reinterpret_cast<u32x4*>(out + row * ldo + col) = pack8(f);
   }
 }
 
@@ -216,8 +242,23 @@ extern "C" int lx2v_quant_fp8_rowwise(const uint16_t* x, int64_t ldx, uint8_t* o
   LX2V_REQUIRE(ldx % 8 == 0 && ldo % 8 == 0 && ldx >= dim && ldo >= dim, LX2V_EINVAL, "quant_fp8: row strides must be multiples of 8 and >= dim");
   LX2V_REQUIRE(lx2v_aligned16(x) && (reinterpret_cast<uintptr_t>(out) & 7u) == 0, LX2V_EINVAL, "quant_fp8: x must be 16-byte, out 8-byte aligned");
   if (rows == 0) return LX2V_OK;
-  hipLaunchKernelGGL(quant_fp8_rowwise_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo, scale,
-                     rows, dim);
+  const int nchunks = dim >> 3;
+  int lpr = 64;
+  if (nchunks <= 32 && (nchunks & (nchunks - 1)) == 0) lpr = nchunks;  // short rows share a wave
+  const int64_t rows_per_block = 4 * (64 / lpr);
+  hipLaunchKernelGGL(quant_fp8_rowwise_kernel, dim3((unsigned)((rows + rows_per_block - 1) / rows_per_block)), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo,
+                     scale, rows, dim, lpr);
   LX2V_CHECK_LAUNCH("quant_fp8");
+  return LX2V_OK;
+}
+
+extern "C" int lx2v_dequant_fp8_rowwise(const uint8_t* q, int64_t ldq, const float* scale, uint16_t* out, int64_t ldo, int64_t rows, int dim, void* stream) {
+  LX2V_REQUIRE(q && out && scale, LX2V_EINVAL, "dequant_fp8: null tensor");
+  LX2V_REQUIRE(rows >= 0 && dim > 0 && dim % 8 == 0, LX2V_EINVAL, "dequant_fp8: dim=%d must be a positive multiple of 8", dim);
+  LX2V_REQUIRE(ldq % 8 == 0 && ldo % 8 == 0 && ldq >= dim && ldo >= dim, LX2V_EINVAL, "dequant_fp8: row strides must be multiples of 8 and >= dim");
+  LX2V_REQUIRE(lx2v_aligned16(out) && (reinterpret_cast<uintptr_t>(q) & 7u) == 0, LX2V_EINVAL, "dequant_fp8: out must be 16-byte, q 8-byte aligned");
+  if (rows == 0) return LX2V_OK;
+  hipLaunchKernelGGL(dequant_fp8_rowwise_kernel, dim3(ew_blocks(rows * (dim >> 3))), dim3(256), 0, (hipStream_t)stream, q, ldq, scale, out, ldo, rows, dim);
+  LX2V_CHECK_LAUNCH("dequant_fp8");
   return LX2V_OK;
 }

@@ -36,6 +36,7 @@ _SIGNATURES = {
     "lx2v_lincomb_f32": [_P, _I64, _I, _P, _P, _P],
     "lx2v_cfg_combine_f32": [_P, _P, _P, _F, _I64, _P],
     "lx2v_quant_fp8_rowwise": [_P, _I64, _P, _I64, _P, _I64, _I, _P],
+    "lx2v_dequant_fp8_rowwise": [_P, _I64, _P, _P, _I64, _I64, _I, _P],
     "lx2v_gemm_fp8": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _P, _I64, _P, _P],
 }
 EXPORTS = tuple(_SIGNATURES) + ("lx2v_abi_version", "lx2v_last_error")
@@ -309,6 +310,21 @@ def quant_fp8_rowwise(x: torch.Tensor):
     scale = torch.empty((rows,), dtype=torch.float32, device=x.device)
     _check(load().lx2v_quant_fp8_rowwise(x.data_ptr(), x.stride(0), q.data_ptr(), q.stride(0), scale.data_ptr(), rows, dim, _stream()), "lx2v_quant_fp8_rowwise")
     return q, scale
+
+
+def dequant_fp8_rowwise(q: torch.Tensor, scale: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """e4m3 [rows, dim] and fp32 scale [rows] -> bf16 [rows, dim] = q.to(bf16) * scale.to(bf16)."""
+    if not q.is_cuda or q.dtype != torch.float8_e4m3fn or q.dim() != 2 or q.stride(1) != 1:
+        raise Lx2vError("dequant_fp8: q must be a GPU float8_e4m3fn [rows, dim] tensor with a contiguous inner dimension")
+    rows, dim = q.shape
+    scale = _vec_f32("dequant_fp8.scale", scale, rows, q)
+    if out is None:
+        out = torch.empty((rows, dim), dtype=torch.bfloat16, device=q.device)
+    _need_bf16_cuda("dequant_fp8.out", out)
+    if tuple(out.shape) != (rows, dim) or out.stride(1) != 1:
+        raise Lx2vError(f"dequant_fp8: out must be [{rows}, {dim}] with a contiguous inner dimension")
+    _check(load().lx2v_dequant_fp8_rowwise(q.data_ptr(), q.stride(0), scale.data_ptr(), out.data_ptr(), out.stride(0), rows, dim, _stream()), "lx2v_dequant_fp8_rowwise")
+    return out
 
 
 def gemm_fp8(a8: torch.Tensor, a_scale: torch.Tensor, w8: torch.Tensor, w_scale: torch.Tensor, bias=None, epilogue: int = EPI_NONE,

@@ -265,7 +265,7 @@ class WanTransformerInfer:
             if self.fused_block and hasattr(par, "apply_segmented") and phase.self_attn_o.supports_kseg:
                 # the all-to-all result stays in its [source rank][S/N][H/N*d] receive layout; the
                 # output projection reads it as a K-segmented A operand (no gather copy)
-                recv, kseg, kseg_stride = par.apply_segmented(q, k, v, attention_module=phase.self_attn_1, seq_p_group=self.seq_p_group)
+                recv, kseg, kseg_stride = par.apply_segmented(q, k, v, attention_module=phase.self_attn_1, seq_p_group=self.seq_p_group, use_fp8_comm=self.seq_p_fp8_comm)
                 phase.self_attn_o.apply_residual_(recv, x, gate_msa, a_kseg=kseg, a_kseg_stride=kseg_stride)
                 return None
             attn_out = par.apply(q=q, k=k, v=v, img_qkv_len=S, cu_seqlens_qkv=cu, attention_module=phase.self_attn_1,

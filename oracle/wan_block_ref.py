@@ -342,3 +342,18 @@ def linear_fp8(x: torch.Tensor, w_q: torch.Tensor, w_scale: torch.Tensor, b: Opt
     x_q, x_scale = quant_fp8_rowwise(x)
     y = (x_q.float() @ w_q.float().t()) * x_scale[:, None] * w_scale[None, :]
     return y if b is None else y + b
+
+
+def dequant_fp8_rowwise(q: torch.Tensor, scale: torch.Tensor, dtype=torch.bfloat16) -> torch.Tensor:
+    """`dequant_fp8_vllm` (lightx2v/utils/quant_utils.py:185-186): q.to(dtype) * scale.to(dtype), one
+    scale per row."""
+    return q.to(dtype) * scale.to(dtype)[:, None]
+
+
+def fp8_comm_roundtrip(x: torch.Tensor) -> torch.Tensor:
+    """What an activation [tokens, heads, d] looks like after the fp8 Ulysses payload
+    (lightx2v/common/ops/attn/ulysses_attn.py:59-73): quantised per (token, head) row of d values,
+    moved (a pure permutation), widened back to bf16 (the activation dtype in production)."""
+    t, h, d = x.shape
+    q, s = quant_fp8_rowwise(x.reshape(-1, d))
+    return dequant_fp8_rowwise(q, s, torch.bfloat16).to(x.dtype).view(t, h, d)

@@ -21,7 +21,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, out_dir, fused):
+def _worker(rank, world, port, out_dir, fused, fp8_comm=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -36,7 +36,7 @@ def _worker(rank, world, port, out_dir, fused):
     c = case_inputs(rec)
     _, seq_idx, seq_group, _ = ulysses.make_groups(1, world)
     cfg = {"num_layers": 1, "num_heads": c["heads"], "dim": c["dim"], "task": "t2v", "seq_parallel": True, "seq_p_group": seq_group,
-           "parallel": {"seq_p_size": world, "seq_p_attn_type": "hip_ulysses"}, "fused_block": fused}
+           "parallel": {"seq_p_size": world, "seq_p_attn_type": "hip_ulysses", "seq_p_fp8_comm": fp8_comm}, "fused_block": fused}
     W = L.WanTransformerWeights(cfg)
     wd = dict(c["w"]); wd.update(c["hw"])
     W.load(wd); W.to_cuda()
@@ -53,7 +53,7 @@ def _worker(rank, world, port, out_dir, fused):
                                     context=c["context"].to(torch.bfloat16).to(dev))
     out = inf.infer_block(W.blocks[0], pre.x, pre)
     torch.cuda.synchronize()
-    torch.save(out.float().cpu(), os.path.join(out_dir, f"o{rank}_{int(fused)}.pt"))
+    torch.save(out.float().cpu(), os.path.join(out_dir, f"o{rank}_{int(fused)}{'_fp8' if fp8_comm else ''}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -78,6 +78,29 @@ def test_sequence_parallel_block_two_ranks_one_gpu(cuda, tmp_path, fused):
     ref = R.block_forward(xp, c["embed0"], c["context"], c["w"], cs, c["heads"])[:S]
     assert cos(got, ref) >= 0.9999
     assert cos(got - c["x"], ref - c["x"]) >= 0.995
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_sequence_parallel_block_fp8_payload(cuda, tmp_path, fused):
+    """`seq_p_fp8_comm`: q, k, v and the attention output cross the exchange as e4m3 + per-(token, head)
+    scales.  Against the fp32 oracle of the unsharded block the result stays inside the fp8 payload's
+    error (and differs from the bf16-payload run, i.e. the switch is live)."""
+    from oracle import wan_block_ref as R
+    from tests.util import case_inputs, cos, load_golden
+
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), fused, True), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), fused, False), nprocs=world, join=True)
+    c = case_inputs(load_golden("small_d512_g3x5x7"))
+    got8 = torch.cat([torch.load(os.path.join(str(tmp_path), f"o{r}_{int(fused)}_fp8.pt")) for r in range(world)])[:c["S"]]
+    got = torch.cat([torch.load(os.path.join(str(tmp_path), f"o{r}_{int(fused)}.pt")) for r in range(world)])[:c["S"]]
+    S, D = c["S"], c["dim"]
+    xp = torch.zeros(S + 1, D); xp[:S] = c["x"]
+    cs = torch.cat([c["cos_sin"], torch.zeros(1, 1, c["cos_sin"].shape[-1], dtype=c["cos_sin"].dtype)])
+    ref = R.block_forward(xp, c["embed0"], c["context"], c["w"], cs, c["heads"])[:S]
+    assert not torch.equal(got8, got)
+    assert cos(got8, ref) >= 0.9999
+    assert cos(got8 - c["x"], ref - c["x"]) >= 0.99
 
 
 def _hy_worker(rank, world, port, out_dir):

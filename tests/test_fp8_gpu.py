@@ -28,6 +28,23 @@ def test_quant_fp8_rowwise_bit_exact(cuda, rows, dim):
     assert torch.equal(q.cpu().view(torch.uint8), q_ref.view(torch.uint8))
 
 
+@pytest.mark.parametrize("rows,dim", [(1000, 128), (37, 64), (300, 256), (5, 8), (129, 1536)])
+def test_short_row_quant_and_dequant_bit_exact(cuda, rows, dim):
+    """Rows of one head (the fp8 Ulysses payload): several rows share a wave; the inverse widens
+    with the bf16-rounded scale."""
+    x = _rand((rows, dim), 300 + rows)
+    x[rows // 2] = 0
+    q_ref, s_ref = R.quant_fp8_rowwise(x)
+    q, s = hip.quant_fp8_rowwise(x.to(cuda))
+    assert torch.equal(s.cpu(), s_ref) and torch.equal(q.cpu().view(torch.uint8), q_ref.view(torch.uint8))
+    back = hip.dequant_fp8_rowwise(q, s)
+    assert torch.equal(back.cpu(), R.dequant_fp8_rowwise(q_ref, s_ref, torch.bfloat16))
+    # into a strided destination (a column range of a wider buffer)
+    buf = torch.zeros(rows, dim + 16, dtype=torch.bfloat16, device=cuda)
+    hip.dequant_fp8_rowwise(q, s, out=buf[:, :dim])
+    assert torch.equal(buf[:, :dim], back) and buf[:, dim:].abs().max().item() == 0
+
+
 @pytest.mark.parametrize("M,N,K", [(16, 64, 128), (300, 512, 256), (1000, 1536, 1536), (257, 264, 384), (64, 5120, 13824)])
 def test_gemm_fp8_matches_quantised_domain_product(cuda, M, N, K):
     a, w = _rand((M, K), 80), _rand((N, K), 81, 0.05)

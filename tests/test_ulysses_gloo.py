@@ -65,12 +65,21 @@ def _worker(rank, world, port, cfg_p, seq_p, out_dir):
         uly.apply(ql[:, :H - 1], kl[:, :H - 1], vl[:, :H - 1], img_qkv_len=Sl, cu_seqlens_qkv=torch.tensor([0, Sl]), attention_module=_OracleAttn(), seq_p_group=seq_group)
     except ValueError:
         raised = True
+    # fp8 payload: q, k, v and the attention output are quantised per (token, head) around the exchanges
+    rt = R.fp8_comm_roundtrip
+    uly8 = ulysses.HipUlyssesAttnWeight(pack_fn=_torch_pack, quant_fn=R.quant_fp8_rowwise,
+                                        dequant_fn=lambda q8, sc, out: out.copy_(R.dequant_fp8_rowwise(q8, sc, torch.bfloat16)))
+    out8 = uly8.apply(ql, kl, vl, img_qkv_len=Sl, cu_seqlens_qkv=torch.tensor([0, Sl], dtype=torch.int32),
+                      attention_module=_OracleAttn(), seq_p_group=seq_group, use_fp8_comm=True)
+    ref8 = rt(R.sdpa(rt(q), rt(k), rt(v)).view(S, H, d)).view(S, H * d).chunk(seq_p)[seq_idx]
+    err8 = ((out8 - ref8).abs().max() / ref8.abs().max()).item()  # a value on a rounding boundary may land one e4m3 step away
+    cos8 = R.cosine(out8, ref8)
     ok_cfg = True
     if cfg_p == 2:
         local = torch.full((4, 3), float(cfg_idx + 1))  # cond rank holds 1s, uncond rank 2s
         comb = ulysses.cfg_parallel_combine(local, cfg_group, 5.0)
         ok_cfg = torch.allclose(comb, torch.full((4, 3), 2.0 + 5.0 * (1.0 - 2.0)))
-    torch.save({"err": err, "err2": err2, "raised": raised or seq_p == 1, "ok_cfg": ok_cfg}, os.path.join(out_dir, f"r{rank}.pt"))
+    torch.save({"err": err, "err2": err2, "raised": raised or seq_p == 1, "ok_cfg": ok_cfg, "err8": err8, "cos8": cos8, "fp8_changes": (out8 - out).abs().max().item()}, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -83,6 +92,7 @@ def test_ulysses_and_cfg_groups_gloo(tmp_path, cfg_p, seq_p):
         res = torch.load(os.path.join(str(tmp_path), f"r{r}.pt"))
         assert res["err"] < 1e-5 and res["err2"] < 1e-5, res
         assert res["raised"] and res["ok_cfg"], res
+        assert res["err8"] <= 0.07 and res["cos8"] >= 0.9999 and res["fp8_changes"] > 0, res
 
 
 def _txt_worker(rank, world, port, golden_path, out_dir):
