@@ -191,6 +191,7 @@ class WanTransformerInfer:
 
     def set_scheduler(self, scheduler):
         self.scheduler = scheduler
+        self.scheduler.transformer_infer = self  # common/transformer_infer/transformer_infer.py:10-12
 
     def get_scheduler_values(self):
         self.cos_sin = self.scheduler.cos_sin

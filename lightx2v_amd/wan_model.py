@@ -197,8 +197,19 @@ class WanScheduler:
         self.noise_pred: Optional[torch.Tensor] = None
         self.infer_condition = True
         self.step_index = 0
+        # which forwards ran their blocks (feature caching; BaseScheduler scheduler.py:10, WanScheduler :30)
+        self.caching_records = [True] * self.infer_steps
+        self.caching_records_2 = [True] * self.infer_steps
+        self.transformer_infer = None
         self.cos_sin = None
         self.seq_p_group = config.get("seq_p_group") if config.get("seq_parallel") else None
+
+    def clear(self):
+        """Drop cached features between clips (schedulers/wan/feature_caching/scheduler.py:8-9)."""
+        if self.transformer_infer is not None and hasattr(self.transformer_infer, "clear"):
+            self.transformer_infer.clear()
+        self.caching_records = [True] * self.infer_steps
+        self.caching_records_2 = [True] * self.infer_steps
 
     # scheduler.py:49-76
     def prepare(self, seed, latent_shape, image_encoder_output=None, latents: Optional[torch.Tensor] = None):
@@ -327,7 +338,15 @@ class WanModel:
         self.pre_weight = WanPreWeights(cfg)
         self.transformer_weights = WanTransformerWeights(cfg)
         self.pre_infer = WanPreInfer(cfg)
-        self.transformer_infer = WanTransformerInfer(cfg)
+        caching = cfg.get("feature_caching", "NoCaching")
+        if caching == "NoCaching":
+            self.transformer_infer = WanTransformerInfer(cfg)
+        elif caching == "Tea":
+            from .wan_caching import WanTransformerInferTeaCaching
+
+            self.transformer_infer = WanTransformerInferTeaCaching(cfg)
+        else:
+            raise NotImplementedError(f"feature_caching={caching!r}: built are 'NoCaching' and 'Tea'")
         self.post_infer = WanPostInfer(cfg)
         self.seq_p_group = cfg.get("seq_p_group") if cfg.get("seq_parallel") else None
         self.cfg_p_group = cfg.get("cfg_p_group") if cfg.get("cfg_parallel") else None

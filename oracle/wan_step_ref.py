@@ -253,3 +253,74 @@ def sample_loop_two_experts(models, boundary: float, guides, latents0: torch.Ten
         traj.append(latents)
         picks.append(which)
     return latents, traj, picks
+
+
+# --------------------------------------------------------------------------- TeaCache
+class TeaCache:
+    """Skip logic of `WanTransformerInferTeaCaching`
+    (lightx2v/models/networks/wan/infer/feature_caching/transformer_infer.py:25-157): per CFG branch,
+    the relative L1 change of the timestep modulation input (embed0 with `use_ret_steps`, else
+    embed) is rescaled by a degree-4 polynomial and accumulated; while the sum stays under the
+    threshold the blocks are skipped and the previous pass's residual (blocks' output - input) is
+    added to the patch-embedded tokens instead.  The first `ret_steps` and the steps from
+    `cutoff_steps` on are always computed."""
+
+    def __init__(self, infer_steps: int, thresh: float, coefficients, use_ret_steps: bool):
+        self.thresh = thresh
+        self.use_ret_steps = use_ret_steps
+        if use_ret_steps:
+            self.coefficients, self.ret_steps, self.cutoff_steps = coefficients[0], 5, infer_steps
+        else:
+            self.coefficients, self.ret_steps, self.cutoff_steps = coefficients[1], 1, infer_steps - 1
+        self.acc = {True: 0.0, False: 0.0}
+        self.prev_inp = {True: None, False: None}
+        self.prev_residual = {True: None, False: None}
+
+    def should_calc(self, step_index: int, cond: bool, embed: torch.Tensor, embed0: torch.Tensor) -> bool:
+        inp = embed0 if self.use_ret_steps else embed
+        if step_index < self.ret_steps or step_index >= self.cutoff_steps:
+            calc = True
+            self.acc[cond] = 0.0
+        else:
+            prev = self.prev_inp[cond]
+            rel = ((inp - prev).abs().mean() / prev.abs().mean()).item()
+            self.acc[cond] += float(np.poly1d(self.coefficients)(rel))
+            calc = not (self.acc[cond] < self.thresh)
+            if calc:
+                self.acc[cond] = 0.0
+        self.prev_inp[cond] = inp.clone()
+        return calc
+
+
+def forward_teacache(model, latents, t, context, num_heads, num_layers, tea: TeaCache, step_index: int, cond: bool):
+    """`forward` with the blocks replaced by the cached residual when TeaCache says so.  Returns
+    (noise prediction, whether the blocks ran)."""
+    x, embed, embed0, ctx, grid = pre_infer(model, latents, t, context)
+    calc = tea.should_calc(step_index, cond, embed, embed0)
+    if calc:
+        cos_sin = R.build_cos_sin(grid, model["patch_embedding.bias"].shape[0] // num_heads)
+        x0 = x.clone()
+        for i in range(num_layers):
+            x = R.block_forward(x, embed0, ctx, model, cos_sin, num_heads, block_index=i)
+        tea.prev_residual[cond] = x - x0
+    else:
+        x = x + tea.prev_residual[cond]
+    y = R.head_forward(x, embed, model)
+    return unpatchify(y, grid, model["head.head.bias"].shape[0] // 4).float(), calc
+
+
+def sample_loop_teacache(model, latents0, context, context_null, num_heads, num_layers, infer_steps, sample_shift, guide, thresh, coefficients, use_ret_steps):
+    """Denoise loop with TeaCache.  Returns (final latents, per-step latents, records of the
+    conditional branch, records of the unconditional branch)."""
+    sch = UniPC(infer_steps, sample_shift)
+    tea = TeaCache(infer_steps, thresh, coefficients, use_ret_steps)
+    latents, traj, rec, rec2 = latents0, [], [], []
+    for i in range(infer_steps):
+        t = sch.timestep_input(i)
+        cond, c1 = forward_teacache(model, latents, t, context, num_heads, num_layers, tea, i, True)
+        uncond, c2 = forward_teacache(model, latents, t, context_null, num_heads, num_layers, tea, i, False)
+        latents = sch.step(i, cfg_combine(cond, uncond, guide), latents)
+        traj.append(latents)
+        rec.append(c1)
+        rec2.append(c2)
+    return latents, traj, rec, rec2

@@ -145,3 +145,27 @@ def test_two_expert_i2v_loop_against_reference_trajectory(cuda):
     err, c = rel_err(sch.latents, final), cos(sch.latents, final)
     print(f"\ntwo-expert i2v loop: final-latent max-rel-err {err:.3e}, cosine {c:.6f}")
     assert err <= 3e-2 and c >= 0.9995
+
+
+def test_teacache_loop_against_reference_run(cuda):
+    """`feature_caching: "Tea"`: the same forwards skip their blocks as in the reference's run (both
+    CFG branches), and the trajectory stays with the reference's."""
+    rec, meta, model = step_case("step_teacache_d256")
+    inputs = {"text_encoder_output": {k: torch.from_numpy(rec[k]).to(cuda) for k in ("context", "context_null")}}
+    m, sch = _model(meta, model, cuda, keep_latents_dtype_in_scheduler=True, feature_caching="Tea", teacache_thresh=meta["thresh"],
+                    coefficients=meta["coefficients"], use_ret_steps=meta["use_ret_steps"])
+    assert type(m.transformer_infer).__name__ == "WanTransformerInferTeaCaching" and sch.transformer_infer is m.transformer_infer
+    sch.prepare(meta["seed"], meta["latent_shape"], latents=torch.from_numpy(rec["latents0"]))
+    for i in range(meta["steps"]):
+        sch.step_pre(i)
+        m.infer(inputs)
+        sch.step_post()
+        assert cos(sch.latents, torch.from_numpy(rec[f"latents_{i + 1}"])) >= 0.999, i
+    assert sch.caching_records == rec["records"].tolist() and sch.caching_records_2 == rec["records_2"].tolist()
+    final = torch.from_numpy(rec[f"latents_{meta['steps']}"])
+    print(f"\nteacache loop: records {''.join('C' if r else '-' for r in sch.caching_records)}, final-latent max-rel-err {rel_err(sch.latents, final):.3e}")
+    assert rel_err(sch.latents, final) <= 5e-2
+    sch.clear()
+    assert m.transformer_infer.previous_residual_even is None and all(sch.caching_records)
+    with pytest.raises(NotImplementedError):
+        _model(meta, model, cuda, feature_caching="Mag")

@@ -134,3 +134,16 @@ def test_product_scheduler_scalars_equal_restatement(steps, shift):
                 assert (a, b, c) == (float(ra), float(rb), float(rc))
                 assert rk is None and rrk is None or rk == float(rrk)
                 assert rho is None and rrho is None or torch.equal(rho, rrho)
+
+
+def test_teacache_loop_matches_reference_run():
+    """The TeaCache restatement against the reference's `WanTransformerInferTeaCaching` run: same
+    skip pattern on both CFG branches and the same latents after every step."""
+    rec, meta, model = step_case("step_teacache_d256")
+    final, traj, r1, r2 = T.sample_loop_teacache(model, torch.from_numpy(rec["latents0"]), torch.from_numpy(rec["context"]), torch.from_numpy(rec["context_null"]),
+                                                 meta["heads"], meta["layers"], meta["steps"], meta["shift"], meta["guide"], meta["thresh"], meta["coefficients"],
+                                                 meta["use_ret_steps"])
+    assert r1 == rec["records"].tolist() and r2 == rec["records_2"].tolist()
+    assert not all(r1) and sum(r1) > 2
+    for i, lat in enumerate(traj):
+        assert (lat - torch.from_numpy(rec[f"latents_{i + 1}"])).abs().max().item() < 2e-4
