@@ -13,6 +13,10 @@
 // with 4 consecutive output columns of one row (8 contiguous bytes after packing).
 // Epilogue: bias / GELU / gate in fp32 on the accumulators, staged per wave through LDS as
 // bf16, then whole 128-B row segments are written (and the residual read) with 16-B accesses.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -50,6 +54,61 @@ LX2V_DEVICE int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
   const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + (bid >> 3);
+}
+
+// Epilogue shared by both schedules: fp32 math on the accumulators -> per-wave LDS image (bf16) ->
+// whole 128-B row segments.  acc[nt][mt][j] = C'[m = wm*128 + mt*16 + fr][n = wn*64 + nt*16 + fq*4 + j].
+// Every wave of the workgroup must have finished reading the operand tiles in `lds`.
+template <int EPI>
+LX2V_DEVICE void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][8], char* lds, int m0, int n0, int wid, int wm, int wn, int lane) {
+  const int fr = lane & 15, fq = lane >> 4;
+  char* stg = lds + wid * 16384;  // 128 rows x 128 B per wave
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int ncol = n0 + wn * 64 + nt * 16 + fq * 4;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f}, gv = {1.f, 1.f, 1.f, 1.f};
+    if (ncol < p.N) {
+      if (p.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(p.bias + ncol);
+      if (EPI == LX2V_EPI_RESIDUAL && p.gate != nullptr) gv = *reinterpret_cast<const f32x4*>(p.gate + ncol);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = acc[nt][mt][j] + bv[j];
+        if (EPI == LX2V_EPI_GELU_TANH) v[j] = gelu_tanh(v[j]);
+        if (EPI == LX2V_EPI_RESIDUAL) v[j] *= gv[j];
+      }
+      const int r = mt * 16 + fr;                 // row inside the wave's 128-row image
+      const int slot = nt * 4 + fq;               // 8-byte slot inside the 128-B row
+      const int off = r * 128 + ((((slot >> 1) ^ (r & 7)) << 4) | ((slot & 1) << 3));
+      u32x2 pk = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+      *reinterpret_cast<u32x2*>(stg + off) = pk;
+    }
+  }
+  // Each wave reads back only its own image: a wave-level wait on the LDS writes is enough.
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  const int c8 = lane & 7;  // 16-B chunk inside the 128-B row segment
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int r = it * 8 + (lane >> 3);
+    const int gm_ = m0 + wm * 128 + r;
+    const int gn = n0 + wn * 64 + c8 * 8;
+    u32x4 val = *reinterpret_cast<const u32x4*>(stg + r * 128 + ((c8 ^ (r & 7)) << 4));
+    if (gm_ < p.M && gn < p.N) {
+      if (EPI == LX2V_EPI_RESIDUAL) {
+        float a[8], b[8];
+        unpack8(val, a);
+        unpack8(*reinterpret_cast<const u32x4*>(p.resid + (int64_t)gm_ * p.ldr + gn), b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += b[j];
+        val = pack8(a);
+      }
+      *reinterpret_cast<u32x4*>(p.C + (int64_t)gm_ * p.ldc + gn) = val;
+    }
+  }
 }
 
 template <int EPI>
@@ -155,55 +214,230 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const GemmParams p)
     if (!(GEMM_ABL & 4)) __syncthreads();
   }
 
-  // ---- epilogue: fp32 math on accumulators -> per-wave LDS image (bf16) -> row stores ----
-  // acc[nt][mt][j] = C'[m = wm*128 + mt*16 + fr][n = wn*64 + nt*16 + fq*4 + j]
-  char* stg = lds + wid * 16384;  // 128 rows x 128 B per wave
+  gemm_epilogue<EPI>(p, acc, lds, m0, n0, wid, wm, wn, lane);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Ping-pong variant (the default for K >= 128).  Same tile, fragments, swizzle and epilogue; what
+// changes is the schedule.  The 8 waves form two groups (wave rows 0 and 1; on every SIMD one wave of
+// each).  A K-tile is computed in four phases, one 64 x 32 quadrant of the wave's 128 x 64 output
+// each: [LDS fragment reads + 2 LDS-DMA instructions] barrier [16 MFMAs] barrier.  Group 1 runs one
+// barrier behind group 0, so on each SIMD one wave's reads and DMA issue overlap the other wave's
+// MFMAs.  Staging units are the row sets one phase reads (16 KiB each):
+//     Am0 = A rows {0-63, 128-191}   read in phase 1        Bn0 = W rows {64w + 0-31}   read in phase 1 (kept for phase 4)
+//     Am1 = A rows {64-127, 192-255} read in phase 3        Bn1 = W rows {64w + 32-63}  read in phase 2
+// and travel in the fixed stream order Am0(t) Bn0(t) Bn1(t) Am1(t) Am0(t+1) ..., one unit per phase:
+//     phase 1 of tile u issues Bn1(u+1), phase 2 Am1(u+1), phase 3 Am0(u+2), phase 4 Bn0(u+2)
+// -- each into a region whose last read lies at least two phases back -- and every phase waits with
+// vmcnt(8): all but the newest four units have landed, which is exactly what the NEXT phase reads.
+// A unit is read one phase after the wait + barrier that retires it (LDS-DMA data is ordered for
+// another wave's ds_read only by the issuing wave's vmcnt followed by a barrier).
+constexpr int A_BUF = BM * BK * 2;           // 32 KiB per operand per buffer
+constexpr int W_BASE = 2 * A_BUF;            // LDS: [A buf0][A buf1][W buf0][W buf1]
+enum { TILE_FULL = 0, TILE_PENULT = 1, TILE_LAST = 2 };
+
+template <int EPI>
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16_pp_kernel(const GemmParams p) {
+  __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 2, wn = wid & 3;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int t = xcd_remap(blockIdx.x, nwg);
+  const int group_sz = GROUP_M * p.tiles_n;
+  const int g = t / group_sz;
+  const int first_m = g * GROUP_M;
+  const int gm = min(p.tiles_m - first_m, GROUP_M);
+  const int in_g = t - g * group_sz;
+  const int tile_m = first_m + in_g % gm;
+  const int tile_n = in_g / gm;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- staging: unit U in {0: Am0, 1: Bn0, 2: Bn1, 3: Am1}, two DMA instructions (i) per unit ----
+  // unit row r = i*64 + wid*8 + (lane >> 3), physical chunk = lane & 7; 8 consecutive unit rows are 8
+  // consecutive tile rows, so each instruction fills 1 KiB of contiguous LDS (lane-linear).
+  // Sources are a wave-uniform base (tile origin + K offset, scalar registers) plus a per-lane
+  // 32-bit byte offset inside the tile's row panel.
+  uint32_t soff[4][2];
+  int dst[4][2];  // LDS byte offset of the wave's first lane, inside buffer 0
+  const char* a_base = reinterpret_cast<const char*>(p.A + (int64_t)m0 * p.lda);
+  const char* w_base = reinterpret_cast<const char*>(p.W + (int64_t)n0 * p.ldw);
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-    const int ncol = n0 + wn * 64 + nt * 16 + fq * 4;
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f}, gv = {1.f, 1.f, 1.f, 1.f};
-    if (ncol < p.N) {
-      if (p.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(p.bias + ncol);
-      if (EPI == LX2V_EPI_RESIDUAL && p.gate != nullptr) gv = *reinterpret_cast<const f32x4*>(p.gate + ncol);
+  for (int U = 0; U < 4; ++U)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r0 = i * 64 + wid * 8, r = r0 + (lane >> 3);
+      const bool is_a = (U == 0 || U == 3);
+      const int row = is_a ? (r >> 6) * 128 + (U == 3 ? 64 : 0) + (r & 63) : (r >> 5) * 64 + (U == 2 ? 32 : 0) + (r & 31);
+      const int row0 = is_a ? (r0 >> 6) * 128 + (U == 3 ? 64 : 0) + (r0 & 63) : (r0 >> 5) * 64 + (U == 2 ? 32 : 0) + (r0 & 31);
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      const int rr = is_a ? min(row, p.M - 1 - m0) : min(row, p.N - 1 - n0);  // rows past the edge re-read the last one
+      soff[U][i] = (uint32_t)((int64_t)rr * (is_a ? p.lda : p.ldw) * 2 + chunk * 16);
+      dst[U][i] = (is_a ? 0 : W_BASE) + row0 * 128;
     }
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-      float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        v[j] = acc[nt][mt][j] + bv[j];
-        if (EPI == LX2V_EPI_GELU_TANH) v[j] = gelu_tanh(v[j]);
-        if (EPI == LX2V_EPI_RESIDUAL) v[j] *= gv[j];
+  // element offset of a K-tile inside A (segment aware), advanced one tile at a time
+  int64_t a_koff_issue = 0, a_within = 0;  // offset of the tile whose Am0 is issued next
+  int64_t a_koff_am1 = 0;                  // offset of the tile whose Am1 is issued next
+  auto a_advance = [&](int64_t& koff, int64_t& within) {
+    koff += BK;
+    if (p.a_kseg != 0) {
+      within += BK;
+      if (within == p.a_kseg) {
+        within = 0;
+        koff += p.a_kseg_stride - p.a_kseg;
       }
-      const int r = mt * 16 + fr;                 // row inside the wave's 128-row image
-      const int slot = nt * 4 + fq;               // 8-byte slot inside the 128-B row
-      const int off = r * 128 + ((((slot >> 1) ^ (r & 7)) << 4) | ((slot & 1) << 3));
-      u32x2 pk = {pack2(v[0], v[1]), pack2(v[2], v[3])};
-      *reinterpret_cast<u32x2*>(stg + off) = pk;
+    }
+  };
+  int64_t am1_within = 0;
+
+  auto issue = [&](int U, int buf, int64_t koff) {
+    const char* base = ((U == 0 || U == 3) ? a_base : w_base) + koff * 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(base + soff[U][i], lds + dst[U][i] + buf * A_BUF);
+  };
+
+  const int fr = lane & 15, fq = lane >> 4;
+  int a_rd[2], w_rd[2];
+  {
+    const int arow = wm * 128 + fr, wrow = wn * 64 + fr;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      a_rd[ks] = arow * 128 + (((ks * 4 + fq) ^ ((arow >> 1) & 7)) << 4);
+      w_rd[ks] = W_BASE + wrow * 128 + (((ks * 4 + fq) ^ ((wrow >> 1) & 7)) << 4);
     }
   }
-  // Each wave reads back only its own image: a wave-level wait on the LDS writes is enough.
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-  const int c8 = lane & 7;  // 16-B chunk inside the 128-B row segment
-#pragma unroll 4
-  for (int it = 0; it < 16; ++it) {
-    const int r = it * 8 + (lane >> 3);
-    const int gm_ = m0 + wm * 128 + r;
-    const int gn = n0 + wn * 64 + c8 * 8;
-    u32x4 val = *reinterpret_cast<const u32x4*>(stg + r * 128 + ((c8 ^ (r & 7)) << 4));
-    if (gm_ < p.M && gn < p.N) {
-      if (EPI == LX2V_EPI_RESIDUAL) {
-        float a[8], b[8];
-        unpack8(val, a);
-        unpack8(*reinterpret_cast<const u32x4*>(p.resid + (int64_t)gm_ * p.ldr + gn), b);
+
+  f32x4 acc[4][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a[j] += b[j];
-        val = pack8(a);
-      }
-      *reinterpret_cast<u32x4*>(p.C + (int64_t)gm_ * p.ldc + gn) = val;
-    }
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;  // >= 2 (checked by the launcher)
+
+  // ---- prologue: Am0(0) Bn0(0) Bn1(0) Am1(0) Am0(1) Bn0(1) ----
+  issue(0, 0, a_koff_issue);
+  issue(1, 0, 0);
+  issue(2, 0, 0);
+  issue(3, 0, a_koff_am1);
+  a_advance(a_koff_issue, a_within);
+  a_advance(a_koff_am1, am1_within);
+  issue(0, 1, a_koff_issue);
+  issue(1, 1, BK);
+  a_advance(a_koff_issue, a_within);  // now the offset of tile 2
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind
+
+  bf16x8 af[4][2], b0[2][2], b1[2][2];
+
+  // One K-tile = four phases.  KIND (the same for every wave): FULL issues all four units, PENULT
+  // (tile nk-2) only the two for tile nk-1, LAST none; the waits shrink with what is left in flight.
+  auto tile = [&](auto buf_c, int u) {
+    constexpr int BUF = decltype(buf_c)::value;
+    const int KIND = u + 2 < nk ? TILE_FULL : (u + 1 < nk ? TILE_PENULT : TILE_LAST);  // wave-uniform
+    constexpr int RD = BUF * A_BUF;  // immediate offset of this tile's buffer for the fragment reads
+    const char* base = lds;
+    // ---- phase 1: quadrant (m0, n0) ----
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) b0[nt][ks] = *reinterpret_cast<const bf16x8*>(base + w_rd[ks] + RD + nt * 2048);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) af[mt][ks] = *reinterpret_cast<const bf16x8*>(base + a_rd[ks] + RD + mt * 2048);
+    if (KIND != TILE_LAST) issue(2, BUF ^ 1, (int64_t)(u + 1) * BK);
+    if (KIND == TILE_LAST) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[nt][ks], af[mt][ks], acc[nt][mt], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 2: quadrant (m0, n1) ----
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) b1[nt][ks] = *reinterpret_cast<const bf16x8*>(base + w_rd[ks] + RD + (nt + 2) * 2048);
+    if (KIND != TILE_LAST) issue(3, BUF ^ 1, a_koff_am1);
+    if (KIND == TILE_LAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[nt + 2][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[nt][ks], af[mt][ks], acc[nt + 2][mt], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    a_advance(a_koff_am1, am1_within);
+    // ---- phase 3: quadrant (m1, n1) ----
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) af[mt][ks] = *reinterpret_cast<const bf16x8*>(base + a_rd[ks] + RD + (mt + 4) * 2048);
+    if (KIND == TILE_FULL) issue(0, BUF, a_koff_issue);
+    if (KIND == TILE_FULL) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (KIND == TILE_PENULT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[nt + 2][mt + 4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[nt][ks], af[mt][ks], acc[nt + 2][mt + 4], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 4: quadrant (m1, n0), operands already in registers ----
+    if (KIND == TILE_FULL) issue(1, BUF, (int64_t)(u + 2) * BK);
+    if (KIND == TILE_FULL) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (KIND == TILE_PENULT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[nt][mt + 4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[nt][ks], af[mt][ks], acc[nt][mt + 4], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    if (KIND == TILE_FULL) a_advance(a_koff_issue, a_within);
+  };
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  for (int u = 0; u < nk; u += 2) {
+    tile(B0{}, u);
+    if (u + 1 < nk) tile(B1{}, u + 1);
   }
+  if (wm == 0) __builtin_amdgcn_s_barrier();  // group 0 gives back the barrier group 1 spent at the start
+
+  gemm_epilogue<EPI>(p, acc, lds, m0, n0, wid, wm, wn, lane);
 }
 
 }  // namespace
@@ -245,10 +479,22 @@ extern "C" int lx2v_gemm_bf16(const uint16_t* A, int64_t lda, int64_t a_kseg, in
   LX2V_REQUIRE(nwg < (1LL << 31), LX2V_EUNSUP, "gemm: too many tiles");
   const dim3 grid((unsigned)nwg), block(NTHREADS);
   hipStream_t st = (hipStream_t)stream;
-  switch (epilogue) {
-    case LX2V_EPI_NONE: hipLaunchKernelGGL(gemm_bf16_kernel<LX2V_EPI_NONE>, grid, block, 0, st, p); break;
-    case LX2V_EPI_GELU_TANH: hipLaunchKernelGGL(gemm_bf16_kernel<LX2V_EPI_GELU_TANH>, grid, block, 0, st, p); break;
-    default: hipLaunchKernelGGL(gemm_bf16_kernel<LX2V_EPI_RESIDUAL>, grid, block, 0, st, p); break;
+  static const bool simple = [] {
+    const char* e = getenv("LX2V_GEMM_KERNEL");  // "simple": the one-barrier-per-K-tile schedule (A/B switch)
+    return e != nullptr && strcmp(e, "simple") == 0;
+  }();
+  if (simple || K < 2 * BK) {
+    switch (epilogue) {
+      case LX2V_EPI_NONE: hipLaunchKernelGGL(gemm_bf16_kernel<LX2V_EPI_NONE>, grid, block, 0, st, p); break;
+      case LX2V_EPI_GELU_TANH: hipLaunchKernelGGL(gemm_bf16_kernel<LX2V_EPI_GELU_TANH>, grid, block, 0, st, p); break;
+      default: hipLaunchKernelGGL(gemm_bf16_kernel<LX2V_EPI_RESIDUAL>, grid, block, 0, st, p); break;
+    }
+  } else {
+    switch (epilogue) {
+      case LX2V_EPI_NONE: hipLaunchKernelGGL(gemm_bf16_pp_kernel<LX2V_EPI_NONE>, grid, block, 0, st, p); break;
+      case LX2V_EPI_GELU_TANH: hipLaunchKernelGGL(gemm_bf16_pp_kernel<LX2V_EPI_GELU_TANH>, grid, block, 0, st, p); break;
+      default: hipLaunchKernelGGL(gemm_bf16_pp_kernel<LX2V_EPI_RESIDUAL>, grid, block, 0, st, p); break;
+    }
   }
   LX2V_CHECK_LAUNCH("gemm");
   return LX2V_OK;
