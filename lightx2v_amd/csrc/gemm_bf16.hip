@@ -26,7 +26,7 @@ constexpr int NTHREADS = 512;
 constexpr int TILE_BYTES = BM * BK * 2;  // 32 KiB, same for A and W
 constexpr int GROUP_M = 8;               // tile rasterisation: 8 row-panels share one column sweep
 #ifndef GEMM_ABL
-#define GEMM_ABL 0  // timing ablations (wrong results): 1 no load wait, 2 no staging, 4 no barrier
+#define GEMM_ABL 0  // timing ablations (wrong results): 1 no load wait, 2 no staging, 4 no barrier, 8 no priority raise (ping-pong), 16 no fragment reads (ping-pong)
 #endif
 
 struct GemmParams {
@@ -295,6 +295,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_pp_kernel(const GemmParams
   int64_t am1_within = 0;
 
   auto issue = [&](int U, int buf, int64_t koff) {
+    if (GEMM_ABL & 2) return;
     const char* base = ((U == 0 || U == 3) ? a_base : w_base) + koff * 2;
 #pragma unroll
     for (int i = 0; i < 2; ++i) glds16(base + soff[U][i], lds + dst[U][i] + buf * A_BUF);
@@ -358,14 +359,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_pp_kernel(const GemmParams
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
+    if (!(GEMM_ABL & 8)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[nt][ks], af[mt][ks], acc[nt][mt], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
+    if (!(GEMM_ABL & 8)) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     // ---- phase 2: quadrant (m0, n1) ----
@@ -379,14 +380,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_pp_kernel(const GemmParams
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
+    if (!(GEMM_ABL & 8)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[nt + 2][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[nt][ks], af[mt][ks], acc[nt + 2][mt], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
+    if (!(GEMM_ABL & 8)) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     a_advance(a_koff_am1, am1_within);
@@ -401,14 +402,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_pp_kernel(const GemmParams
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
+    if (!(GEMM_ABL & 8)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[nt + 2][mt + 4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[nt][ks], af[mt][ks], acc[nt + 2][mt + 4], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
+    if (!(GEMM_ABL & 8)) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     // ---- phase 4: quadrant (m1, n0), operands already in registers ----
@@ -417,14 +418,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_pp_kernel(const GemmParams
     else if (KIND == TILE_PENULT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
+    if (!(GEMM_ABL & 8)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[nt][mt + 4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[nt][ks], af[mt][ks], acc[nt][mt + 4], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
+    if (!(GEMM_ABL & 8)) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     if (KIND == TILE_FULL) a_advance(a_koff_issue, a_within);
@@ -479,10 +480,8 @@ extern "C" int lx2v_gemm_bf16(const uint16_t* A, int64_t lda, int64_t a_kseg, in
   LX2V_REQUIRE(nwg < (1LL << 31), LX2V_EUNSUP, "gemm: too many tiles");
   const dim3 grid((unsigned)nwg), block(NTHREADS);
   hipStream_t st = (hipStream_t)stream;
-  static const bool simple = [] {
-    const char* e = getenv("LX2V_GEMM_KERNEL");  // "simple": the one-barrier-per-K-tile schedule (A/B switch)
-    return e != nullptr && strcmp(e, "simple") == 0;
-  }();
+  const char* sched = getenv("LX2V_GEMM_KERNEL");  // "simple": the one-barrier-per-K-tile schedule (A/B switch, read per call)
+  const bool simple = sched != nullptr && strcmp(sched, "simple") == 0;
   if (simple || K < 2 * BK) {
     switch (epilogue) {
       case LX2V_EPI_NONE: hipLaunchKernelGGL(gemm_bf16_kernel<LX2V_EPI_NONE>, grid, block, 0, st, p); break;

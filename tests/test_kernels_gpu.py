@@ -104,6 +104,34 @@ def test_gemm_bias(cuda, M, N, K):
     assert (out2.float().cpu() - R.linear(a.float(), w.float(), None)).abs().max().item() <= BF16_EPS * ref.abs().max().item() + 1e-3
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(4000, 2048, 2048, "none"), (1111, 1536, 8960, "gelu"), (3000, 5120, 5120, "resid"), (700, 512, 192, "none")])
+def test_gemm_schedules_agree_bitwise(cuda, M, N, K, epi, monkeypatch):
+    """The ping-pong schedule accumulates every output in the same order as the one-barrier
+    schedule, so the two must agree bit for bit -- a stale or early-read LDS tile would not.
+    Repeated launches with other work in flight in between (different timing each time)."""
+    a, w = _rand((M, K), 40), _rand((N, K), 41, 0.05)
+    b = 0.1 * torch.randn(N, generator=torch.Generator().manual_seed(42))
+    gate = torch.randn(N, generator=torch.Generator().manual_seed(43))
+    resid = _rand((M, N), 44).to(cuda)
+    ad, wd, bd = a.to(cuda), w.to(cuda), b.to(cuda)
+
+    def run():
+        if epi == "gelu":
+            return hip.gemm(ad, wd, bd, epilogue=hip.EPI_GELU_TANH)
+        if epi == "resid":
+            return hip.gemm(ad, wd, bd, epilogue=hip.EPI_RESIDUAL, resid=resid, gate=gate.to(cuda))
+        return hip.gemm(ad, wd, bd)
+
+    monkeypatch.setenv("LX2V_GEMM_KERNEL", "simple")
+    ref = run()
+    monkeypatch.delenv("LX2V_GEMM_KERNEL")
+    noise = torch.empty(64 << 20, dtype=torch.uint8, device=cuda)
+    for i in range(6):
+        if i % 2:
+            noise.fill_(i)  # HBM traffic in flight while the GEMM starts
+        assert torch.equal(run(), ref), i
+
+
 def test_gemm_mfma_operand_orientation_identity(cuda):
     """A = I against an ASYMMETRIC W catches a transposed accumulator write-back."""
     n = 256
