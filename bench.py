@@ -50,6 +50,7 @@ TEXT_LEN = 512
 TEXT_DIM = 4096  # umT5-xxl features
 LATENT_CHANNELS = 16
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X
+MFMA_FP8_PEAK_TFLOPS = 5000.0   # dense fp8 (block-scaled e4m3)
 GUIDE_SCALE = 5.0
 
 
@@ -173,6 +174,19 @@ def cpu_baseline(D, H, F, full_S, layers, threads):
     }
 
 
+def attn_peak(args):
+    return MFMA_BF16_PEAK_TFLOPS if args.attn == "bf16" else MFMA_FP8_PEAK_TFLOPS
+
+
+def arithmetic_label(args):
+    """The JSON line's `dtype` and the metric-name suffix for the non-headline arithmetic choices."""
+    if args.linear == "bf16" and args.attn == "bf16":
+        return "bf16", ""
+    lin = "bf16 Linears" if args.linear == "bf16" else "fp8 Linears (W8A8 e4m3)"
+    att = "bf16 attention" if args.attn == "bf16" else "fp8 attention (block-scaled e4m3)"
+    return f"{lin} + {att}", " (" + ", ".join(x for x in ("fp8 Linears" if args.linear == "fp8" else "", "fp8 attention" if args.attn == "fp8" else "") if x) + ")"
+
+
 def run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu):
     """HunyuanVideo-1.5 (4-step distilled, no CFG): one step = all double-stream blocks + final layer on
     synthetic pre-infer outputs (image tokens, text tokens, conditioning vector) + the Euler update.
@@ -195,6 +209,7 @@ def run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu):
         _, seq_idx, seq_group, _ = ulysses.make_groups(1, seq_p)
     cfg = {"mm_double_blocks_depth": layers, "heads_num": H, "hidden_size": D, "task": "t2v",
            "dit_quant_scheme": "hip-bf16" if args.linear == "bf16" else "hip-fp8",
+           "attn_type": "hip_flash_attn" if args.attn == "bf16" else "hip_fp8_attn",
            "seq_parallel": seq_p > 1, "seq_p_group": seq_group, "parallel": {"seq_p_size": seq_p, "seq_p_attn_type": "hip_ulysses"}}
     W = L.HunyuanVideo15TransformerWeights(cfg)
     g = torch.Generator(device=dev).manual_seed(1234)  # same seed on every rank: weights are replicated
@@ -271,17 +286,18 @@ def run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu):
     step_flops = (4.0 * Sj * Sj * D + 2.0 * Sj * D * (4 * D + 2 * F)) * layers
     frames = {31: 121, 21: 81}[grid[0]]
     return {
-        "metric": f"s/denoise-step {args.model} {args.res}{frames}f" + ("" if args.linear == "bf16" else " (fp8 Linears)"),
+        "metric": f"s/denoise-step {args.model} {args.res}{frames}f" + arithmetic_label(args)[1],
         "value": s_per_step, "unit": "s/denoise-step", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": s_per_step * 1e3, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
-        "dtype": "bf16" if args.linear == "bf16" else "fp8 Linears (W8A8 e4m3) + bf16 attention",
+        "dtype": arithmetic_label(args)[0],
         "data": "synthetic image/text tokens and conditioning vector, random-init weights of the named architecture"
                 + ("" if (backend == "nccl" and not share_gpu) else f" [REHEARSAL: backend={backend} share_gpu={share_gpu}, not a measurement]"),
         "config": {"workload": f"{args.model} {args.res} x{frames}f: {S} image + {HY_TEXT_LEN} text tokens, {layers} double-stream blocks + final layer + Euler update, no CFG (distilled schedule); pre-infer not included",
                    "parallelism": f"seq_p{seq_p} (ulysses)", "tokens": S, "dim": D, "heads": H, "ffn_dim": F, "layers": layers},
         "step_tflops": step_flops / 1e12, "achieved_tflops_per_gpu": step_flops / s_per_step / 1e12 / world,
-        "roofline": {"kernel": "attn_fwd_w4_kernel<false> (joint image+text attention)", "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+        "roofline": {"kernel": ("attn_fwd_w4_kernel<false>" if args.attn == "bf16" else "attn_fwd_fp8_kernel<false> + quantisation pre-pass") + " (joint image+text attention)",
+                     "bound": "mfma", "achieved": achieved, "peak": attn_peak(args),
+                     "unit": "TFLOP/s", "frac": achieved / attn_peak(args), "traffic": None,
                      "launch_ms": attn_ms, "flops_per_launch": attn_flops, "launches_timed": n_launches},
     }
 
@@ -296,7 +312,9 @@ def main():
     ap.add_argument("--layout", default=None, help="cfg_p x seq_p, e.g. 2x4 (default: 1x1, 2x1, 2x2, 2x4 for 1/2/4/8 GPUs)")
     ap.add_argument("--layers", type=int, default=None, help="override the layer count (debug only; the JSON line then says so)")
     ap.add_argument("--linear", default="bf16", choices=["bf16", "fp8"],
-                    help="arithmetic of the blocks' Linears: bf16 (the headline configuration) or W8A8 e4m3 (the reference's fp8 schemes); attention stays bf16")
+                    help="arithmetic of the blocks' Linears: bf16 (the headline configuration) or W8A8 e4m3 (the reference's fp8 schemes)")
+    ap.add_argument("--attn", default="bf16", choices=["bf16", "fp8"],
+                    help="self-attention arithmetic: bf16 (the headline configuration) or block-scaled e4m3 on the fp8 MFMA (where the reference would run a quantised backend)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -374,6 +392,7 @@ def main():
            "in_dim": LATENT_CHANNELS, "out_dim": LATENT_CHANNELS, "freq_dim": 256, "infer_steps": 50, "sample_shift": 5.0,
            "sample_guide_scale": GUIDE_SCALE, "enable_cfg": True, "run_device": "cuda",
            "dit_quant_scheme": "hip-bf16" if args.linear == "bf16" else "hip-fp8",
+           "self_attn_1_type": "hip_flash_attn" if args.attn == "bf16" else "hip_fp8_attn",
            "cfg_parallel": cfg_p > 1, "cfg_p_group": cfg_group,
            "seq_parallel": seq_p > 1, "seq_p_group": seq_group, "parallel": {"seq_p_size": seq_p, "cfg_p_size": cfg_p, "seq_p_attn_type": "hip_ulysses"}}
     model = build_model(cfg, dev, seed=1234)  # same seed on every rank: weights are replicated
@@ -437,17 +456,19 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "s/denoise-step Wan2.1-T2V-14B 720p81f" if (args.model, args.res, args.linear) == ("wan2.1-t2v-14b", "720p", "bf16") else f"s/denoise-step {args.model} {args.res}81f" + ("" if args.linear == "bf16" else " (fp8 Linears)"),
+            "metric": "s/denoise-step Wan2.1-T2V-14B 720p81f" if (args.model, args.res, args.linear, args.attn) == ("wan2.1-t2v-14b", "720p", "bf16", "bf16") else f"s/denoise-step {args.model} {args.res}81f" + arithmetic_label(args)[1],
             "value": s_per_step, "unit": "s/denoise-step", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": s_per_step * 1e3, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
-            "dtype": "bf16" if args.linear == "bf16" else "fp8 Linears (W8A8 e4m3) + bf16 attention", "data": "synthetic latents and text features, random-init weights of the named architecture"
+            "dtype": arithmetic_label(args)[0], "data": "synthetic latents and text features, random-init weights of the named architecture"
                     + ("" if (backend == "nccl" and not share_gpu) else f" [REHEARSAL: backend={backend} share_gpu={share_gpu}, not a measurement]"),
             "config": {"workload": f"{args.model} {args.res} x81f: {S} tokens, full denoise step (pre-infer, {layers} blocks + head, unpatchify) x 2 CFG forwards + CFG combine + UniPC update, text len {TEXT_LEN}",
                        "parallelism": f"cfg_p{cfg_p} x seq_p{seq_p} (ulysses)", "tokens": S, "dim": D, "heads": H, "ffn_dim": F, "layers": layers},
             "step_tflops": step_flops / 1e12,
             "achieved_tflops_per_gpu": step_flops / s_per_step / 1e12 / world,
-            "roofline": {"kernel": "attn_fwd_w4_kernel<false> (self-attention)", "bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": measured_traffic(S_pad, H // seq_p) if n_launches == layers * 2 * args.steps // cfg_p else None,
+            "roofline": {"kernel": "attn_fwd_w4_kernel<false> (self-attention)" if args.attn == "bf16" else "attn_fwd_fp8_kernel<false> + quantisation pre-pass (self-attention)",
+                         "bound": "mfma", "achieved": achieved, "peak": attn_peak(args),
+                         "unit": "TFLOP/s", "frac": achieved / attn_peak(args),
+                         "traffic": measured_traffic(S_pad, H // seq_p) if (args.attn == "bf16" and n_launches == layers * 2 * args.steps // cfg_p) else None,
                          "launch_ms": attn_ms, "flops_per_launch": attn_flops, "launches_timed": n_launches},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -157,6 +157,26 @@ int lx2v_lincomb_f32(float* out, int64_t n, int terms, const float* const* x, co
 int lx2v_cfg_combine_f32(float* out, const float* cond, const float* uncond, float guide_scale,
                          int64_t n, void* stream);
 
+/* ==== fp8 attention on the CDNA4 block-scaled fp8 MFMA ===================================== */
+
+/* ---- softmax(q k^T * scale) v with both contractions in e4m3 --------------------------------
+ * Same tensors and result layout as lx2v_attn_fwd_bf16 (bf16 in, bf16 out, no mask, head_dim 128).
+ * A quantisation pre-pass (part of this call) writes into `workspace`: q*scale*log2(e) and k as
+ * e4m3 with one power-of-two (E8M0) scale per (token, head, 32 channels); v transposed per 64-key
+ * tile with one E8M0 scale per (channel, 32 keys).  P is rounded to e4m3 in registers; all
+ * accumulation is fp32.  `workspace` must hold lx2v_attn_fp8_workspace_bytes(sq, skv, heads) bytes,
+ * 256-byte aligned; the library allocates nothing.
+ * Stands where the reference selects a quantised attention backend (SageAttn2Weight,
+ * lightx2v/common/ops/attn/sage_attn.py:36-64: int8 QK^T + fp8 PV from the sageattention wheel);
+ * the quantisation scheme here is CDNA4's MX block format, not that wheel's, and the reference
+ * holds no fixture for either -- results are checked against the fp32 softmax and an emulation of
+ * this scheme. */
+int64_t lx2v_attn_fp8_workspace_bytes(int64_t sq, int64_t skv, int heads);
+int lx2v_attn_fwd_fp8(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk,
+                      const uint16_t* v, int64_t ldv, uint16_t* out, int64_t ldo,
+                      int64_t sq, int64_t skv, int heads, int head_dim, float scale,
+                      void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ==== fp8 (OCP e4m3) W8A8 Linear on the CDNA4 fp8 MFMA ===================================== */
 
 /* ---- row-wise dynamic quantisation: scale[r] = max|x[r,:]| / 448 ; out[r,:] = e4m3(x[r,:] / scale[r]) ----

@@ -147,6 +147,24 @@ static void bench_attn(int S, int H, int iters, int skv = -1, bool rope = false)
   if (table) hipFree(table);
 }
 
+static void bench_attn_fp8(int S, int H, int iters) {
+  const size_t n = (size_t)S * H * 128;
+  uint16_t* q = dev_normal(n, 1, 1.0f);
+  uint16_t* k = dev_normal(n, 2, 1.0f);
+  uint16_t* v = dev_normal(n, 3, 1.0f);
+  uint16_t* o;
+  HIPCHK(hipMalloc(&o, n * 2));
+  const int64_t wsb = lx2v_attn_fp8_workspace_bytes(S, S, H);
+  void* ws;
+  HIPCHK(hipMalloc(&ws, (size_t)wsb));
+  const int64_t ld = (int64_t)H * 128;
+  auto run = [&] { LXCHK(lx2v_attn_fwd_fp8(q, ld, k, ld, v, ld, o, ld, S, S, H, 128, 1.0f / sqrtf(128.f), ws, wsb, nullptr)); };
+  const float ms = time_ms(run, iters);
+  const double flops = 4.0 * S * (double)S * H * 128;
+  printf("attn_fp8 S=%d H=%d (quantisation pre-pass included) : %.3f ms  %.1f TFLOP/s (%.1f%% of 5000)\n", S, H, ms, flops / ms * 1e-9, flops / ms * 1e-9 / 50.0);
+  hipFree(q); hipFree(k); hipFree(v); hipFree(o); hipFree(ws);
+}
+
 static void bench_gemm(int M, int N, int K, int epi, int iters) {
   uint16_t* a = dev_normal((size_t)M * K, 4, 1.0f);
   uint16_t* w = dev_normal((size_t)N * K, 5, 0.02f);
@@ -243,6 +261,7 @@ int main(int argc, char** argv) {
   HIPCHK(hipGetDeviceProperties(&prop, 0));
   printf("device: %s  CUs=%d  clock=%d MHz\n", prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000);
   if (!strcmp(what, "selfattn")) bench_attn(S, H, iters);
+  if (!strcmp(what, "selfattn8")) bench_attn_fp8(S, H, iters);
   if (!strcmp(what, "gemm1")) bench_gemm(S, D, D, 0, iters);
   if (!strcmp(what, "attn") || !strcmp(what, "all")) {
     bench_attn(S, H, iters);

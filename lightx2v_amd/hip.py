@@ -35,6 +35,8 @@ _SIGNATURES = {
     "lx2v_silu_bf16": [_P, _P, _I64, _P],
     "lx2v_lincomb_f32": [_P, _I64, _I, _P, _P, _P],
     "lx2v_cfg_combine_f32": [_P, _P, _P, _F, _I64, _P],
+    "lx2v_attn_fp8_workspace_bytes": [_I64, _I64, _I],
+    "lx2v_attn_fwd_fp8": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I, _I, _F, _P, _I64, _P],
     "lx2v_quant_fp8_rowwise": [_P, _I64, _P, _I64, _P, _I64, _I, _P],
     "lx2v_dequant_fp8_rowwise": [_P, _I64, _P, _P, _I64, _I64, _I, _P],
     "lx2v_gemm_fp8": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _P, _I64, _P, _P],
@@ -61,7 +63,7 @@ def load() -> ctypes.CDLL:
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_int
+        fn.restype = ctypes.c_int64 if name == "lx2v_attn_fp8_workspace_bytes" else ctypes.c_int
     lib.lx2v_abi_version.restype = ctypes.c_int
     lib.lx2v_last_error.restype = ctypes.c_char_p
     _lib = lib
@@ -213,6 +215,40 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional[
                                    out.data_ptr(), out.stride(0), sq, skv, H, d, float(scale), _ptr(rope_cos_sin), _stream())
     _check(st, "lx2v_attn_fwd_bf16")
     return out
+
+
+def attn_fwd_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional[float] = None, out: Optional[torch.Tensor] = None,
+                 workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`attn_fwd` with both contractions in block-scaled e4m3 (bf16 in / bf16 out).  `workspace`: a
+    uint8 GPU tensor of at least `attn_fp8_workspace_bytes` bytes (allocated here when absent)."""
+    for n, t in (("q", q), ("k", k), ("v", v)):
+        _need_bf16_cuda("attn_fp8." + n, t)
+        if t.dim() != 3 or t.stride(1) != t.shape[2]:
+            raise Lx2vError(f"attn_fp8.{n}: expected [S,H,d] with heads contiguous inside a token, got shape {tuple(t.shape)} strides {t.stride()}")
+    sq, H, d = q.shape
+    skv = k.shape[0]
+    if k.shape[1:] != (H, d) or v.shape != k.shape:
+        raise Lx2vError(f"attn_fp8: q {tuple(q.shape)} k {tuple(k.shape)} v {tuple(v.shape)} do not agree")
+    if scale is None:
+        scale = d ** -0.5
+    if out is None:
+        out = torch.empty((sq, H * d), dtype=q.dtype, device=q.device)
+    need = attn_fp8_workspace_bytes(sq, skv, H)
+    if workspace is None:
+        workspace = torch.empty(need, dtype=torch.uint8, device=q.device)
+    if not workspace.is_cuda or workspace.dtype != torch.uint8 or not workspace.is_contiguous() or workspace.numel() < need:
+        raise Lx2vError(f"attn_fp8: workspace must be a contiguous uint8 GPU tensor of >= {need} bytes")
+    st = load().lx2v_attn_fwd_fp8(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), out.data_ptr(), out.stride(0),
+                                  sq, skv, H, d, float(scale), workspace.data_ptr(), workspace.numel(), _stream())
+    _check(st, "lx2v_attn_fwd_fp8")
+    return out
+
+
+def attn_fp8_workspace_bytes(sq: int, skv: int, heads: int) -> int:
+    n = load().lx2v_attn_fp8_workspace_bytes(sq, skv, heads)
+    if n < 0:
+        raise Lx2vError(f"attn_fp8_workspace_bytes: bad shape sq={sq} skv={skv} heads={heads}")
+    return int(n)
 
 
 def ulysses_pack_qkv(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, world: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:

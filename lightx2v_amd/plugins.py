@@ -98,6 +98,35 @@ class HipFlashAttnWeight(_AttnBase):
         return hip.attn_fwd(q, k, v, rope_cos_sin=rope)
 
 
+@ATTN_WEIGHT_REGISTER("hip_fp8_attn")
+class HipFp8AttnWeight(_AttnBase):
+    """The same attention with both contractions on the block-scaled fp8 MFMA (q, k in e4m3 with a
+    power-of-two scale per 32 channels, v per 32 keys, P rounded to e4m3; fp32 accumulation).
+    Selected where the reference would select a quantised backend such as `sage_attn2`
+    (lightx2v/common/ops/attn/sage_attn.py:36-64).  The quantisation workspace is kept between calls
+    and grows on demand."""
+
+    def __init__(self):
+        super().__init__()
+        self._workspace: Optional[torch.Tensor] = None
+
+    def apply(self, q, k, v, drop_rate=0, attn_mask=None, causal=False, cu_seqlens_q=None, cu_seqlens_kv=None,
+              max_seqlen_q=None, max_seqlen_kv=None, model_cls=None):
+        if drop_rate not in (0, 0.0) or attn_mask is not None or causal:
+            raise NotImplementedError("hip_fp8_attn: dropout, masks and causal attention are not part of the block path")
+        if q.dim() == 4:
+            if q.shape[0] != 1:
+                raise NotImplementedError("hip_fp8_attn: batch > 1 is not part of the block path")
+            q, k, v = q[0], k[0], v[0]
+        for name, cu in (("cu_seqlens_q", cu_seqlens_q), ("cu_seqlens_kv", cu_seqlens_kv)):
+            if cu is not None and cu.numel() != 2:
+                raise NotImplementedError(f"hip_fp8_attn: {name} must describe one sequence, got {cu.numel() - 1}")
+        need = hip.attn_fp8_workspace_bytes(q.shape[0], k.shape[0], q.shape[1])
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != q.device:
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=q.device)
+        return hip.attn_fwd_fp8(q, k, v, workspace=self._workspace)
+
+
 # ----------------------------------------------------------------------------------- matmul
 @MM_WEIGHT_REGISTER("hip-bf16")
 class HipMMWeight:

@@ -48,7 +48,7 @@ def test_adopt_into_foreign_registries():
 
     added = registry_factory.adopt_into(Foreign)
     assert "hip-bf16" in Foreign.MM_WEIGHT_REGISTER and "hip_flash_attn" in Foreign.ATTN_WEIGHT_REGISTER
-    assert added["ATTN_WEIGHT_REGISTER"] == ["hip_flash_attn", "hip_ulysses"]
+    assert added["ATTN_WEIGHT_REGISTER"] == ["hip_flash_attn", "hip_fp8_attn", "hip_ulysses"]
     assert registry_factory.adopt_into(Foreign) == {}  # idempotent
 
 
