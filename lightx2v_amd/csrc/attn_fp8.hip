@@ -19,10 +19,11 @@
 // the same elements of scale block 1 (a block = 32 consecutive k).  The scale of block b is read
 // from lane (r, half b), byte `opsel` of the scale register.
 //
-// A quantisation pre-pass writes, per head and 64-key tile, one 16.5 KiB blob that is already the
-// LDS image (K rows swizzled for conflict-free ds_read_b128, K scales, V^T rows swizzled, V scales);
-// staging a tile is a linear copy.  Workgroup = 8 waves x 32 query rows; K/V blobs double-buffered
-// in LDS through registers (loads of tile t+2 in flight while tile t is consumed).
+// A quantisation pre-pass writes, per head and 64-key tile, one 16.75 KiB blob that is already the
+// LDS image (K rows swizzled for conflict-free ds_read_b128, K scales, V^T rows swizzled, V scales;
+// every scale sits in the byte an immediate `opsel` picks, so no lane extracts one); staging a tile
+// is a linear copy, done by LDS-DMA.  Workgroup = 8 waves x 32 query rows; the blobs are
+// double-buffered in LDS, tile t+1 is in flight while tile t is consumed.
 #include "attn_common.h"
 
 using namespace lx2v_attn;
@@ -31,7 +32,7 @@ namespace {
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
-constexpr int K_DATA = 0, K_SCALE = 8192, V_DATA = 8448, V_SCALE = 16640, TILE_BLOB = 16896;
+constexpr int K_DATA = 0, K_SCALE = 8192, V_DATA = 8704, V_SCALE = 16896, TILE_BLOB = 17152;
 constexpr int UNIT_SCALE = 127;  // E8M0 byte of 2^0
 
 // Smallest power of two 2^e with amax / 2^e <= 448 (the e4m3 maximum), from the bits of amax:
@@ -83,7 +84,10 @@ __global__ __launch_bounds__(256) void mxq_rows_kernel(const uint16_t* __restric
     const int key = (int)(token & 63);
     uint8_t* blob = out + ((int64_t)head * tiles + tile) * TILE_BLOB;
     *reinterpret_cast<u32x2*>(blob + K_DATA + key * 128 + (((c16 >> 1) ^ ((key >> 1) & 7)) << 4) + (c16 & 1) * 8) = q;
-    if ((c16 & 3) == 0) blob[K_SCALE + key * 4 + (c16 >> 2)] = (uint8_t)e8;
+    if ((c16 & 3) == 0) {  // block b = c16 >> 2 = 2 ks + h is byte ks of the dword lane half h reads
+      const int b = c16 >> 2;
+      blob[K_SCALE + (key * 2 + (b & 1)) * 4 + (b >> 1)] = (uint8_t)e8;
+    }
   } else {
     const int64_t row = token * heads + head;
     *reinterpret_cast<u32x2*>(out + row * HD + c16 * 8) = q;
@@ -139,6 +143,10 @@ struct Fp8AttnParams {
   int sq, skv, heads, nqb, tiles;
 };
 
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+LX2V_DEVICE void glds16(const void* g, void* l) { __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)l, 16, 0, 0); }
+
 LX2V_DEVICE i32x8 frag32(const char* p0, const char* p1) {
   const u32x4 a = *reinterpret_cast<const u32x4*>(p0), b = *reinterpret_cast<const u32x4*>(p1);
   return i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_fp8_kernel(const Fp8AttnPar
   // ---- Q fragments (B operand of S^T): per 64-channel step ks the lane holds channels 16 h .. +15 of
   // both 32-channel blocks (bytes 0-15: block 2 ks, bytes 16-31: block 2 ks + 1) and the scale of block 2 ks + h ----
   i32x8 qf[2];
-  int qsc[2];
+  int qsc;
   {
     const uint8_t* qp = p.q8 + ((int64_t)qrow_c * p.heads + head) * HD + 16 * h;
 #pragma unroll
@@ -170,23 +178,18 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_fp8_kernel(const Fp8AttnPar
       qf[ks] = i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
     }
     const uint32_t sc = *reinterpret_cast<const uint32_t*>(p.qs + ((int64_t)qrow_c * p.heads + head) * 4);
-    qsc[0] = (int)((sc >> (8 * h)) & 0xffu);
-    qsc[1] = (int)((sc >> (8 * (2 + h))) & 0xffu);
+    qsc = (int)(((sc >> (8 * h)) & 0xffu) | (((sc >> (8 * (2 + h))) & 0xffu) << 8));  // byte ks = scale of block 2 ks + h
   }
 
-  // ---- staging: a tile blob is copied linearly, 16 B per thread and step ----
-  const __amdgpu_buffer_rsrc_t kv_rs = make_rsrc(p.kv + (int64_t)head * p.tiles * TILE_BLOB, (uint32_t)((int64_t)p.tiles * TILE_BLOB));
-  u32x4 st0, st1, st2;
-  auto load_tile = [&](int t) __attribute__((always_inline)) {
-    st0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(kv_rs, tid * 16, t * TILE_BLOB, 0));
-    st1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(kv_rs, (tid + 512) * 16, t * TILE_BLOB, 0));
-    if (tid < 32) st2 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(kv_rs, (tid + 1024) * 16, t * TILE_BLOB, 0));
-  };
-  auto write_tile = [&](auto bufc) __attribute__((always_inline)) {
+  // ---- staging: a tile blob is copied linearly by LDS-DMA, 16 B per lane and instruction ----
+  const char* kv_base = reinterpret_cast<const char*>(p.kv) + (int64_t)head * p.tiles * TILE_BLOB;
+  const int wave = __builtin_amdgcn_readfirstlane(wid);
+  auto issue_tile = [&](auto bufc, int t) __attribute__((always_inline)) {
     char* base = lds + decltype(bufc)::value * TILE_BLOB;
-    *reinterpret_cast<u32x4*>(base + tid * 16) = st0;
-    *reinterpret_cast<u32x4*>(base + (tid + 512) * 16) = st1;
-    if (tid < 32) *reinterpret_cast<u32x4*>(base + (tid + 1024) * 16) = st2;
+    const char* src = kv_base + (int64_t)t * TILE_BLOB;
+    glds16(src + (uint32_t)(tid * 16), base + wave * 1024);
+    glds16(src + (uint32_t)((tid + 512) * 16), base + 8192 + wave * 1024);
+    if (tid < 48) glds16(src + (uint32_t)((tid + 1024) * 16), base + 16384);
   };
 
   // ---- fragment read offsets ----
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_fp8_kernel(const Fp8AttnPar
   for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
     for (int i = 0; i < 2; ++i) k_rd[ks][i] = K_DATA + r32 * 128 + (((4 * ks + 2 * i + h) ^ ((r32 >> 1) & 7)) << 4);
-  const int ks_rd = K_SCALE + r32 * 4;
+  const int ks_rd = K_SCALE + (r32 * 2 + h) * 4;
   // V^T (A operand of O^T): d = 32 db + r32, slots 32 h .. +31 = chunks 2 h, 2 h + 1 (swizzled by (d >> 2) & 3);
   // bytes 0-15 are keys of the tile's first 32 (scale group 0), bytes 16-31 of its last 32 (group 1);
   // this lane supplies the scale of group h
@@ -221,22 +224,17 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_fp8_kernel(const Fp8AttnPar
   auto tile = [&](auto bufc, int t) {
     constexpr int BUF = decltype(bufc)::value;
     const char* base = lds + BUF * TILE_BLOB;
+    if (t + 1 < nt) issue_tile(IntC<BUF ^ 1>{}, t + 1);  // that buffer's last reader finished before the barrier just passed
     // ---- S^T - m ----
     f32x16 s[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      const uint32_t sc = *reinterpret_cast<const uint32_t*>(base + ks_rd + kb * 128);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      const int ksc = *reinterpret_cast<const int*>(base + ks_rd + kb * 256);
+      static_for<0, 2>([&](auto ksc_) {
+        constexpr int ks = decltype(ksc_)::value;
         const i32x8 a = frag32(base + k_rd[ks][0] + kb * 4096, base + k_rd[ks][1] + kb * 4096);
-        const int ksc = (int)((sc >> (8 * (2 * ks + h))) & 0xffu);
-        s[kb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, qf[ks], ks == 0 ? negm : s[kb], 0, 0, 0, ksc, 0, qsc[ks]);
-      }
-    }
-    // ---- stage tile t+1 into the other buffer, issue the loads of tile t+2 ----
-    if (t + 1 < nt) {
-      write_tile(IntC<BUF ^ 1>{});
-      if (t + 2 < nt) load_tile(t + 2);
+        s[kb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, qf[ks], ks == 0 ? negm : s[kb], 0, 0, ks, ksc, ks, qsc);
+      });
     }
     // ---- online softmax ----
     if (ragged && t == nt - 1) {
@@ -256,7 +254,7 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_fp8_kernel(const Fp8AttnPar
     i32x8 pf;
     float lsum;
     auto exps = [&]() __attribute__((always_inline)) {
-      lsum = 0.f;
+      f32x2 acc2 = {0.f, 0.f};  // packed adds: two lanes of the sum per instruction
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -267,8 +265,10 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_fp8_kernel(const Fp8AttnPar
           int pk = __builtin_amdgcn_cvt_pk_fp8_f32(e[0], e[1], 0, false);
           pk = __builtin_amdgcn_cvt_pk_fp8_f32(e[2], e[3], pk, true);
           pf[kb * 4 + w] = pk;
-          lsum += (e[0] + e[1]) + (e[2] + e[3]);
+          acc2 += f32x2{e[0], e[1]};
+          acc2 += f32x2{e[2], e[3]};
         }
+      lsum = acc2[0] + acc2[1];
     };
     if (t != 0) exps();
     if (t == 0 || __any(!(lsum <= 64.f))) {
@@ -296,18 +296,18 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_fp8_kernel(const Fp8AttnPar
     }
     l_run += lsum;
     // ---- O^T += V^T P^T ----
-    const uint32_t vsc = *reinterpret_cast<const uint32_t*>(base + vs_rd);
-#pragma unroll
-    for (int db = 0; db < 4; ++db) {
+    const int vsc = *reinterpret_cast<const int*>(base + vs_rd);
+    static_for<0, 4>([&](auto dbc) {
+      constexpr int db = decltype(dbc)::value;
       const i32x8 a = frag32(base + v_rd[0] + db * 2048, base + v_rd[1] + db * 2048);
-      o[db] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, pf, o[db], 0, 0, 0, (int)((vsc >> (8 * db)) & 0xffu), 0, UNIT_SCALE);
-    }
+      o[db] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, pf, o[db], 0, 0, db, vsc, 0, UNIT_SCALE);
+    });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile t+1 has landed
     __syncthreads();
   };
 
-  load_tile(0);
-  write_tile(IntC<0>{});
-  if (nt > 1) load_tile(1);
+  issue_tile(IntC<0>{}, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   {
     int t = 0;

@@ -74,7 +74,7 @@ def test_fp8_attention_plugin_and_workspace_checks(cuda):
     b = plug.apply(q=q.to(cuda)[:64], k=k.to(cuda), v=v.to(cuda))  # smaller call re-uses the workspace
     assert a.shape == (128, 256) and b.shape == (64, 256) and torch.equal(a[:64], b)
     need = hip.attn_fp8_workspace_bytes(128, 128, 2)
-    assert need == 128 * 2 * 132 + 2 * 2 * 16896
+    assert need == 128 * 2 * 132 + 2 * 2 * 17152
     with pytest.raises(hip.Lx2vError):
         hip.attn_fwd_fp8(q.to(cuda), k.to(cuda), v.to(cuda), workspace=torch.empty(need - 1, dtype=torch.uint8, device=cuda))
     with pytest.raises(NotImplementedError):

@@ -25,21 +25,21 @@ c = 128 ** -0.5 * math.log2(math.e)
 q_ref, qe_ref = A8.mx_quant(q.float() * c)
 print("Q bytes equal:", torch.equal(q8.view(torch.uint8), q_ref.view(torch.uint8)), " Q scales equal:", torch.equal(qs, qe_ref.int()))
 off = ((sq * H * 132 + 255) // 256) * 256
-blob = w[off: off + 16896]
+blob = w[off: off + 17152]
 kd = torch.empty(64, 128, dtype=torch.uint8)
 for key in range(64):
     for ch in range(8):
         p = key * 128 + ((ch ^ ((key >> 1) & 7)) << 4)
         kd[key, ch * 16:(ch + 1) * 16] = blob[p:p + 16]
-ks = blob[8192:8448].view(64, 4).int()
+ks = blob[8192:8704].view(64, 2, 4)[:, :, :2].permute(0, 2, 1).reshape(64, 4).int()  # [key][h][ks] -> block 2 ks + h
 k_ref, ke_ref = A8.mx_quant(k.float())
 print("K bytes equal:", torch.equal(kd, k_ref.view(torch.uint8)[:, 0]), " K scales equal:", torch.equal(ks, ke_ref[:, 0].int()))
 vd = torch.empty(128, 64, dtype=torch.uint8)
 for d in range(128):
     for ch in range(4):
-        p = 8448 + d * 64 + ((ch ^ ((d >> 2) & 3)) << 4)
+        p = 8704 + d * 64 + ((ch ^ ((d >> 2) & 3)) << 4)
         vd[d, ch * 16:(ch + 1) * 16] = blob[p:p + 16]
-vs = blob[16640:16896].view(2, 32, 4).int()  # [h][d&31][d>>5]
+vs = blob[16896:17152].view(2, 32, 4).int()  # [h][d&31][d>>5]
 slots = torch.tensor([32 * (j >> 4) + 8 * ((j & 15) >> 2) + 4 * h + (j & 3) for h in range(2) for j in range(32)])
 vq_ref, ve_ref = A8.mx_quant(v.float()[:, 0], dim=0)  # [key][d], e: [2][d]
 print("V bytes equal:", torch.equal(vd, vq_ref.view(torch.uint8)[slots].t().contiguous()), " V scales equal:",
