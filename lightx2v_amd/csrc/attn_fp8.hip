@@ -33,6 +33,7 @@ namespace {
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 constexpr int K_DATA = 0, K_SCALE = 8192, V_DATA = 8704, V_SCALE = 16896, TILE_BLOB = 17152;
+constexpr int PAIR_BLOB = 2 * TILE_BLOB;  // staging unit: two consecutive tiles (one barrier per unit)
 constexpr int UNIT_SCALE = 127;  // E8M0 byte of 2^0
 
 // Smallest power of two 2^e with amax / 2^e <= 448 (the e4m3 maximum), from the bits of amax:
@@ -154,7 +155,7 @@ LX2V_DEVICE i32x8 frag32(const char* p0, const char* p1) {
 
 template <bool SHORT_KV>
 __global__ __launch_bounds__(NTHREADS) void attn_fwd_fp8_kernel(const Fp8AttnParams p) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * TILE_BLOB];
+  __shared__ __attribute__((aligned(16))) char lds[2 * PAIR_BLOB];  // two staging units of two tiles each
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -181,15 +182,16 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_fp8_kernel(const Fp8AttnPar
     qsc = (int)(((sc >> (8 * h)) & 0xffu) | (((sc >> (8 * (2 + h))) & 0xffu) << 8));  // byte ks = scale of block 2 ks + h
   }
 
-  // ---- staging: a tile blob is copied linearly by LDS-DMA, 16 B per lane and instruction ----
+  // ---- staging: a pair of tile blobs (34 304 B, the tile count is even) is copied linearly by
+  // LDS-DMA, 16 B per lane and instruction: four full instructions and one of 96 lanes ----
   const char* kv_base = reinterpret_cast<const char*>(p.kv) + (int64_t)head * p.tiles * TILE_BLOB;
   const int wave = __builtin_amdgcn_readfirstlane(wid);
-  auto issue_tile = [&](auto bufc, int t) __attribute__((always_inline)) {
-    char* base = lds + decltype(bufc)::value * TILE_BLOB;
+  auto issue_pair = [&](auto bufc, int t) __attribute__((always_inline)) {
+    char* base = lds + decltype(bufc)::value * PAIR_BLOB;
     const char* src = kv_base + (int64_t)t * TILE_BLOB;
-    glds16(src + (uint32_t)(tid * 16), base + wave * 1024);
-    glds16(src + (uint32_t)((tid + 512) * 16), base + 8192 + wave * 1024);
-    if (tid < 48) glds16(src + (uint32_t)((tid + 1024) * 16), base + 16384);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(src + (uint32_t)((tid + 512 * i) * 16), base + 8192 * i + wave * 1024);
+    if (tid < 96) glds16(src + (uint32_t)((tid + 2048) * 16), base + 32768 + wave * 1024);
   };
 
   // ---- fragment read offsets ----
@@ -219,25 +221,54 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_fp8_kernel(const Fp8AttnPar
   float l_run = 0.f;
 
   const int nt = p.tiles;
-  const bool ragged = (p.skv & (KVB - 1)) != 0;
 
-  auto tile = [&](auto bufc, int t) {
-    constexpr int BUF = decltype(bufc)::value;
-    const char* base = lds + BUF * TILE_BLOB;
-    if (t + 1 < nt) issue_tile(IntC<BUF ^ 1>{}, t + 1);  // that buffer's last reader finished before the barrier just passed
-    // ---- S^T - m ----
-    f32x16 s[2];
+  // Stages of one tile (SUB = 0, 1 of the staging unit in LDS buffer BUF).  Fragment reads are issued
+  // in whole batches well ahead of the MFMAs that consume them (the scheduler fences keep them
+  // there): K fragments before the previous tile's O^T MFMAs, V fragments before the exponentials.
+  f32x16 s[2];
+  i32x8 kf[2][2], vf[4], pf;
+  int ksc[2], vsc;
+  auto read_k = [&](auto bufc, auto subc) __attribute__((always_inline)) {
+    const char* base = lds + decltype(bufc)::value * PAIR_BLOB + decltype(subc)::value * TILE_BLOB;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      const int ksc = *reinterpret_cast<const int*>(base + ks_rd + kb * 256);
-      static_for<0, 2>([&](auto ksc_) {
-        constexpr int ks = decltype(ksc_)::value;
-        const i32x8 a = frag32(base + k_rd[ks][0] + kb * 4096, base + k_rd[ks][1] + kb * 4096);
-        s[kb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, qf[ks], ks == 0 ? negm : s[kb], 0, 0, ks, ksc, ks, qsc);
-      });
+      ksc[kb] = *reinterpret_cast<const int*>(base + ks_rd + kb * 256);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) kf[kb][ks] = frag32(base + k_rd[ks][0] + kb * 4096, base + k_rd[ks][1] + kb * 4096);
     }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto read_v = [&](auto bufc, auto subc) __attribute__((always_inline)) {
+    const char* base = lds + decltype(bufc)::value * PAIR_BLOB + decltype(subc)::value * TILE_BLOB;
+    vsc = *reinterpret_cast<const int*>(base + vs_rd);
+#pragma unroll
+    for (int db = 0; db < 4; ++db) vf[db] = frag32(base + v_rd[0] + db * 2048, base + v_rd[1] + db * 2048);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // S^T - m: the two key blocks alternate, so no MFMA waits on the one just issued
+  auto qk = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_s_setprio(1);
+    static_for<0, 2>([&](auto ksc_) {
+      constexpr int ks = decltype(ksc_)::value;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+        s[kb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf[kb][ks], qf[ks], ks == 0 ? negm : s[kb], 0, 0, ks, ksc[kb], ks, qsc);
+    });
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto pv = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_s_setprio(1);
+    static_for<0, 4>([&](auto dbc) {
+      constexpr int db = decltype(dbc)::value;
+      o[db] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[db], pf, o[db], 0, 0, db, vsc, 0, UNIT_SCALE);
+    });
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto softmax = [&](int t) __attribute__((always_inline)) {
     // ---- online softmax ----
-    if (ragged && t == nt - 1) {
+    if ((t + 1) * KVB > p.skv) {  // the last real tile when ragged, and the all-padding tile of an odd count
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -251,7 +282,6 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_fp8_kernel(const Fp8AttnPar
     // holds up to 448).  When some lane exceeds it (or on tile 0, where m is still 0) the row maximum
     // is formed, everything at the old scale -- O, l and this tile's scores -- moves to the new one
     // exactly once, and the exponentials are redone.
-    i32x8 pf;
     float lsum;
     auto exps = [&]() __attribute__((always_inline)) {
       f32x2 acc2 = {0.f, 0.f};  // packed adds: two lanes of the sum per instruction
@@ -295,27 +325,37 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_fp8_kernel(const Fp8AttnPar
       exps();
     }
     l_run += lsum;
-    // ---- O^T += V^T P^T ----
-    const int vsc = *reinterpret_cast<const int*>(base + vs_rd);
-    static_for<0, 4>([&](auto dbc) {
-      constexpr int db = decltype(dbc)::value;
-      const i32x8 a = frag32(base + v_rd[0] + db * 2048, base + v_rd[1] + db * 2048);
-      o[db] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, pf, o[db], 0, 0, db, vsc, 0, UNIT_SCALE);
-    });
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile t+1 has landed
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // One staging unit = two tiles = one barrier.  (Running the two wave groups half a period apart --
+  // strictly alternating MFMA and exponential phases, or carrying one group's second tile over the
+  // barrier -- was measured 5-20 % slower than letting the hardware interleave the waves.)
+  auto pair = [&](auto bufc, int t) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(bufc)::value;
+    if (t + 2 < nt) issue_pair(IntC<BUF ^ 1>{}, t + 2);  // that buffer's last reader finished before the barrier just passed
+    read_k(bufc, IntC<0>{});
+    qk();
+    read_v(bufc, IntC<0>{});
+    softmax(t);
+    read_k(bufc, IntC<1>{});
+    pv();
+    qk();
+    read_v(bufc, IntC<1>{});
+    softmax(t + 1);
+    pv();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next unit has landed
     __syncthreads();
   };
-
-  issue_tile(IntC<0>{}, 0);
+  issue_pair(IntC<0>{}, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   {
     int t = 0;
-    for (; t + 1 < nt; t += 2) {
-      tile(IntC<0>{}, t);
-      tile(IntC<1>{}, t + 1);
+    for (; t + 2 < nt; t += 4) {
+      pair(IntC<0>{}, t);
+      pair(IntC<1>{}, t + 2);
     }
-    if (t < nt) tile(IntC<0>{}, t);
+    if (t < nt) pair(IntC<0>{}, t);
   }
 
   // ---- normalise and store: o[db][i] = O[q0 + r32][32 db + 8 (i>>2) + 4 h + (i&3)] ----
@@ -333,7 +373,7 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_fp8_kernel(const Fp8AttnPar
   }
 }
 
-int64_t tiles_of(int64_t skv) { return (skv + KVB - 1) / KVB; }
+int64_t tiles_of(int64_t skv) { return 2 * ((skv + 2 * KVB - 1) / (2 * KVB)); }  // even: tiles are staged in pairs
 
 }  // namespace
 
