@@ -6,7 +6,7 @@ either bare (`@REG`, key = class name) or with a key (`@REG("name")`); registeri
 The instances carry the reference's names so code written against it reads the same here.
 
 `adopt_into(reference_module)` copies this package's HIP plugins into the reference's own registry
-objects, which is how a LightX2V checkout selects them from its JSON configs (see INTEGRATION.md).
+objects, which is how a LightX2V checkout selects them from its JSON configs.
 """
 
 from __future__ import annotations
