@@ -155,7 +155,7 @@ def cpu_baseline(D, H, F, full_S, layers, threads):
     from oracle import wan_block_ref as R
 
     torch.set_num_threads(threads)
-    grid = (3, 45, 80) if full_S > 20000 else (2, 30, 52)
+    grid = (5, 45, 80) if full_S > 20000 else (4, 30, 52)  # ~10-20 s of CPU work on 16 threads
     S = grid[0] * grid[1] * grid[2]
     w = R.make_block_weights(D, F, seed=0)
     x, context, embed0, _ = R.make_inputs(S, D, TEXT_LEN, seed=0)
