@@ -61,6 +61,34 @@ def test_gemm_fp8_matches_quantised_domain_product(cuda, M, N, K):
     assert cos(out, R.linear(a.float(), w.float(), bias)) >= 0.999
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(3000, 2048, 2048, "none"), (1111, 1536, 8960, "gelu"), (2000, 5120, 5120, "resid"), (700, 512, 384, "none")])
+def test_gemm_fp8_schedules_agree_bitwise(cuda, M, N, K, epi, monkeypatch):
+    """The ping-pong schedule accumulates in the same order as the one-barrier schedule: bit-identical
+    results, across repeated launches with other traffic in flight."""
+    aq, a_s = R.quant_fp8_rowwise(_rand((M, K), 60))
+    wq, w_s = R.quant_fp8_rowwise(_rand((N, K), 61, 0.05))
+    bias = (torch.randn(N, generator=torch.Generator().manual_seed(62)) * 0.1).to(cuda)
+    gate = torch.randn(N, generator=torch.Generator().manual_seed(63)).to(cuda)
+    resid = _rand((M, N), 64).to(cuda)
+    args = (aq.to(cuda), a_s.to(cuda), wq.to(cuda), w_s.to(cuda), bias)
+
+    def run():
+        if epi == "gelu":
+            return hip.gemm_fp8(*args, epilogue=hip.EPI_GELU_TANH)
+        if epi == "resid":
+            return hip.gemm_fp8(*args, epilogue=hip.EPI_RESIDUAL, resid=resid.clone(), gate=gate)
+        return hip.gemm_fp8(*args)
+
+    monkeypatch.delenv("LX2V_GEMM_KERNEL", raising=False)
+    ref = run()
+    monkeypatch.setenv("LX2V_GEMM_KERNEL", "pingpong")
+    noise = torch.empty(64 << 20, dtype=torch.uint8, device=cuda)
+    for i in range(6):
+        if i % 2:
+            noise.fill_(i)
+        assert torch.equal(run(), ref), i
+
+
 def test_gemm_fp8_epilogues_and_plugin(cuda):
     M, N, K = 300, 512, 256
     a, w = _rand((M, K), 90), _rand((N, K), 91, 0.05)
