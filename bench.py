@@ -38,7 +38,12 @@ MODELS = {
     # name: dim, heads, ffn, layers
     "wan2.1-t2v-14b": (5120, 40, 13824, 40),
     "wan2.1-t2v-1.3b": (1536, 12, 8960, 30),
+    # Wan2.2-I2V-A14B: two experts of the 14B architecture (high-noise / low-noise), in_dim 16 + 20
+    "wan2.2-i2v-a14b": (5120, 40, 13824, 40),
 }
+MOE_BOUNDARY = 0.9        # i2v switch point (fraction of 1000 training timesteps)
+MOE_GUIDE = [3.5, 3.5]
+MOE_COND_CHANNELS = 20    # mask (4) + VAE latents of the conditioning image (16)
 HY_MODELS = {
     # name: hidden, heads, mlp, double blocks (HunyuanVideo-1.5 transformer)
     "hunyuan-1.5": (2048, 16, 8192, 54),
@@ -395,7 +400,17 @@ def main():
            "self_attn_1_type": "hip_flash_attn" if args.attn == "bf16" else "hip_fp8_attn",
            "cfg_parallel": cfg_p > 1, "cfg_p_group": cfg_group,
            "seq_parallel": seq_p > 1, "seq_p_group": seq_group, "parallel": {"seq_p_size": seq_p, "cfg_p_size": cfg_p, "seq_p_attn_type": "hip_ulysses"}}
-    model = build_model(cfg, dev, seed=1234)  # same seed on every rank: weights are replicated
+    moe = args.model == "wan2.2-i2v-a14b"
+    if moe:
+        # a 4-step schedule puts steps 0-1 above the boundary and steps 2-3 below it, so one warm-up
+        # and two timed steps run the high-noise expert, then each expert once
+        cfg.update({"task": "i2v", "model_cls": "wan2.2_moe", "in_dim": LATENT_CHANNELS + MOE_COND_CHANNELS, "use_image_encoder": False,
+                    "sample_guide_scale": MOE_GUIDE, "infer_steps": 4})
+        experts = [build_model(cfg, dev, seed=1234), build_model(cfg, dev, seed=4321)]  # same seeds on every rank
+        model = L.MultiModelStruct(experts, cfg, boundary=MOE_BOUNDARY)
+    else:
+        experts = [build_model(cfg, dev, seed=1234)]  # same seed on every rank: weights are replicated
+        model = experts[0]
     sch = L.WanScheduler(cfg)
     model.set_scheduler(sch)
 
@@ -406,7 +421,10 @@ def main():
     sch.prepare(0, latent_shape, latents=torch.randn(*latent_shape, generator=g, device=dev, dtype=torch.float32))
     inputs = {"text_encoder_output": {k: torch.randn(1, TEXT_LEN, TEXT_DIM, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
                                       for k in ("context", "context_null")}}
-    timers = [AttnTimer(model.transformer_weights.blocks[i].compute_phases[0].self_attn_1) for i in range(layers)]
+    if moe:
+        inputs["image_encoder_output"] = {"vae_encoder_out": torch.randn(MOE_COND_CHANNELS, *latent_shape[1:], generator=g, device=dev, dtype=torch.float32)}
+    timers = [AttnTimer(m.transformer_weights.blocks[i].compute_phases[0].self_attn_1) for m in experts for i in range(layers)]
+    picks = []
 
     dbg = os.environ.get("LX2V_BENCH_DEBUG") == "1"
     step_no = [0]
@@ -419,6 +437,8 @@ def main():
         sch.step_pre(step_index=i)
         model.infer(inputs)
         sch.step_post()
+        if moe:
+            picks.append(model.cur_model_index)
         if dbg:
             torch.cuda.synchronize()
             print(f"[rank {rank}] step {i} done, latents finite={bool(torch.isfinite(sch.latents).all())}", flush=True)
@@ -461,7 +481,8 @@ def main():
             "ms_per_step": s_per_step * 1e3, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
             "dtype": arithmetic_label(args)[0], "data": "synthetic latents and text features, random-init weights of the named architecture"
                     + ("" if (backend == "nccl" and not share_gpu) else f" [REHEARSAL: backend={backend} share_gpu={share_gpu}, not a measurement]"),
-            "config": {"workload": f"{args.model} {args.res} x81f: {S} tokens, full denoise step (pre-infer, {layers} blocks + head, unpatchify) x 2 CFG forwards + CFG combine + UniPC update, text len {TEXT_LEN}",
+            "config": {"workload": f"{args.model} {args.res} x81f: {S} tokens, full denoise step (pre-infer, {layers} blocks + head, unpatchify) x 2 CFG forwards + CFG combine + UniPC update, text len {TEXT_LEN}"
+                                   + (f"; two resident experts, switch at t = {MOE_BOUNDARY} (experts of the timed steps: {picks[args.warmup:]}), {MOE_COND_CHANNELS} conditioning channels" if moe else ""),
                        "parallelism": f"cfg_p{cfg_p} x seq_p{seq_p} (ulysses)", "tokens": S, "dim": D, "heads": H, "ffn_dim": F, "layers": layers},
             "step_tflops": step_flops / 1e12,
             "achieved_tflops_per_gpu": step_flops / s_per_step / 1e12 / world,
