@@ -386,10 +386,11 @@ extern "C" int64_t lx2v_attn_fp8_workspace_bytes(int64_t sq, int64_t skv, int he
 extern "C" int lx2v_attn_fwd_fp8(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* v, int64_t ldv,
                                  uint16_t* out, int64_t ldo, int64_t sq, int64_t skv, int heads, int head_dim, float scale,
                                  void* workspace, int64_t workspace_bytes, void* stream) {
-  LX2V_REQUIRE(q && k && v && out && workspace, LX2V_EINVAL, "attn_fwd_fp8: null tensor");
+  LX2V_REQUIRE(sq == 0 || (q && k && v && out && workspace), LX2V_EINVAL, "attn_fwd_fp8: null tensor");
   LX2V_REQUIRE(head_dim == HD, LX2V_EUNSUP, "attn_fwd_fp8: head_dim=%d, only 128 is built", head_dim);
   LX2V_REQUIRE(heads > 0 && sq >= 0 && skv >= 0, LX2V_EINVAL, "attn_fwd_fp8: bad shape sq=%lld skv=%lld heads=%d", (long long)sq, (long long)skv, heads);
   LX2V_REQUIRE(sq < (1LL << 31) && skv < (1LL << 31), LX2V_EUNSUP, "attn_fwd_fp8: sequence lengths must fit in 31 bits");
+  if (sq == 0) return LX2V_OK;
   LX2V_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, LX2V_EINVAL, "attn_fwd_fp8: token strides must be multiples of 8 elements");
   LX2V_REQUIRE(ldq >= (int64_t)heads * HD && ldk >= (int64_t)heads * HD && ldv >= (int64_t)heads * HD && ldo >= (int64_t)heads * HD, LX2V_EINVAL,
                "attn_fwd_fp8: token stride smaller than heads*head_dim");
@@ -397,7 +398,6 @@ extern "C" int lx2v_attn_fwd_fp8(const uint16_t* q, int64_t ldq, const uint16_t*
                "attn_fwd_fp8: tensors must be 16-byte aligned, the workspace 256-byte aligned");
   LX2V_REQUIRE(workspace_bytes >= lx2v_attn_fp8_workspace_bytes(sq, skv, heads), LX2V_EINVAL, "attn_fwd_fp8: workspace of %lld bytes, need %lld", (long long)workspace_bytes,
                (long long)lx2v_attn_fp8_workspace_bytes(sq, skv, heads));
-  if (sq == 0) return LX2V_OK;
   LX2V_REQUIRE(skv > 0, LX2V_EINVAL, "attn_fwd_fp8: skv must be > 0 when sq > 0");
   const int64_t tiles = tiles_of(skv);
   LX2V_REQUIRE(tiles * TILE_BLOB < (1LL << 32), LX2V_EUNSUP, "attn_fwd_fp8: one head's K/V image must stay below 4 GiB");

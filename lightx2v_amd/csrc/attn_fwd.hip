@@ -361,7 +361,7 @@ extern "C" int lx2v_attn_fwd_bf16(const uint16_t* q, int64_t ldq, const uint16_t
                                   const uint16_t* v, int64_t ldv, uint16_t* out, int64_t ldo,
                                   int64_t sq, int64_t skv, int heads, int head_dim, float scale,
                                   const float* rope_cos_sin, void* stream) {
-  LX2V_REQUIRE(q && k && v && out, LX2V_EINVAL, "attn_fwd: null tensor");
+  LX2V_REQUIRE(sq == 0 || (q && k && v && out), LX2V_EINVAL, "attn_fwd: null tensor");
   LX2V_REQUIRE(head_dim == HD, LX2V_EUNSUP, "attn_fwd: head_dim=%d, only 128 is built", head_dim);
   LX2V_REQUIRE(heads > 0 && sq >= 0 && skv >= 0, LX2V_EINVAL, "attn_fwd: bad shape sq=%lld skv=%lld heads=%d", (long long)sq, (long long)skv, heads);
   LX2V_REQUIRE(sq < (1LL << 31) && skv < (1LL << 31), LX2V_EUNSUP, "attn_fwd: sequence lengths must fit in 31 bits");

@@ -447,7 +447,7 @@ extern "C" int lx2v_gemm_bf16(const uint16_t* A, int64_t lda, int64_t a_kseg, in
                               const uint16_t* W, int64_t ldw, const float* bias,
                               uint16_t* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
                               const uint16_t* resid, int64_t ldr, const float* gate, void* stream) {
-  LX2V_REQUIRE(A && W && C, LX2V_EINVAL, "gemm: null tensor");
+  LX2V_REQUIRE(M == 0 || (A && W && C), LX2V_EINVAL, "gemm: null tensor");
   LX2V_REQUIRE(M >= 0 && N > 0 && K > 0, LX2V_EINVAL, "gemm: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
   LX2V_REQUIRE(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), LX2V_EUNSUP, "gemm: dimensions must fit in 31 bits");
   LX2V_REQUIRE(K % BK == 0, LX2V_EUNSUP, "gemm: K=%lld must be a multiple of %d", (long long)K, BK);

@@ -253,7 +253,7 @@ int ew_grid(int64_t work_items) {
 extern "C" int lx2v_ln_modulate_bf16(const uint16_t* x, int64_t ldx, const float* ln_w, const float* ln_b,
                                      const float* scale, const float* shift, uint16_t* out, int64_t ldo,
                                      int64_t rows, int dim, float eps, void* stream) {
-  LX2V_REQUIRE(x && out, LX2V_EINVAL, "ln_modulate: null tensor");
+  LX2V_REQUIRE(rows == 0 || (x && out), LX2V_EINVAL, "ln_modulate: null tensor");
   LX2V_REQUIRE(rows >= 0 && dim > 0, LX2V_EINVAL, "ln_modulate: bad shape rows=%lld dim=%d", (long long)rows, dim);
   LX2V_REQUIRE(dim % 8 == 0 && dim <= 8192, LX2V_EUNSUP, "ln_modulate: dim=%d must be a multiple of 8 and <= 8192", dim);
   LX2V_REQUIRE(ldx % 8 == 0 && ldo % 8 == 0 && ldx >= dim && ldo >= dim, LX2V_EINVAL, "ln_modulate: row strides must be multiples of 8 and >= dim");
@@ -271,7 +271,7 @@ extern "C" int lx2v_ln_modulate_bf16(const uint16_t* x, int64_t ldx, const float
 extern "C" int lx2v_rmsnorm_rope_bf16(const uint16_t* x, int64_t ldx, const float* w, int do_norm,
                                       const float* rope_cos_sin, int head_dim, uint16_t* out, int64_t ldo,
                                       int64_t rows, int dim, float eps, void* stream) {
-  LX2V_REQUIRE(x && out, LX2V_EINVAL, "rmsnorm_rope: null tensor");
+  LX2V_REQUIRE(rows == 0 || (x && out), LX2V_EINVAL, "rmsnorm_rope: null tensor");
   LX2V_REQUIRE(rows >= 0 && dim > 0, LX2V_EINVAL, "rmsnorm_rope: bad shape rows=%lld dim=%d", (long long)rows, dim);
   LX2V_REQUIRE(dim % 8 == 0 && dim <= 8192, LX2V_EUNSUP, "rmsnorm_rope: dim=%d must be a multiple of 8 and <= 8192", dim);
   LX2V_REQUIRE(ldx % 8 == 0 && ldo % 8 == 0 && ldx >= dim && ldo >= dim, LX2V_EINVAL, "rmsnorm_rope: row strides must be multiples of 8 and >= dim");
@@ -295,7 +295,7 @@ extern "C" int lx2v_rmsnorm_rope_bf16(const uint16_t* x, int64_t ldx, const floa
 
 extern "C" int lx2v_gate_residual_bf16(uint16_t* x, int64_t ldx, const uint16_t* y, int64_t ldy,
                                        const float* gate, int64_t rows, int dim, void* stream) {
-  LX2V_REQUIRE(x && y, LX2V_EINVAL, "gate_residual: null tensor");
+  LX2V_REQUIRE(rows == 0 || (x && y), LX2V_EINVAL, "gate_residual: null tensor");
   LX2V_REQUIRE(rows >= 0 && dim > 0 && dim % 8 == 0, LX2V_EINVAL, "gate_residual: dim=%d must be a positive multiple of 8", dim);
   LX2V_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= dim && ldy >= dim, LX2V_EINVAL, "gate_residual: row strides must be multiples of 8 and >= dim");
   LX2V_REQUIRE(lx2v_aligned16(x) && lx2v_aligned16(y), LX2V_EINVAL, "gate_residual: tensors must be 16-byte aligned");
@@ -306,7 +306,7 @@ extern "C" int lx2v_gate_residual_bf16(uint16_t* x, int64_t ldx, const uint16_t*
 }
 
 extern "C" int lx2v_gelu_tanh_bf16(const uint16_t* x, uint16_t* out, int64_t n, void* stream) {
-  LX2V_REQUIRE(x && out, LX2V_EINVAL, "gelu_tanh: null tensor");
+  LX2V_REQUIRE(n == 0 || (x && out), LX2V_EINVAL, "gelu_tanh: null tensor");
   LX2V_REQUIRE(n >= 0 && n % 8 == 0, LX2V_EINVAL, "gelu_tanh: n=%lld must be a multiple of 8", (long long)n);
   LX2V_REQUIRE(lx2v_aligned16(x) && lx2v_aligned16(out), LX2V_EINVAL, "gelu_tanh: tensors must be 16-byte aligned");
   if (n == 0) return LX2V_OK;
@@ -318,7 +318,7 @@ extern "C" int lx2v_gelu_tanh_bf16(const uint16_t* x, uint16_t* out, int64_t n, 
 extern "C" int lx2v_ulysses_pack_qkv_bf16(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk,
                                           const uint16_t* v, int64_t ldv, uint16_t* out, int64_t rows,
                                           int dim, int world, void* stream) {
-  LX2V_REQUIRE(q && k && v && out, LX2V_EINVAL, "ulysses_pack: null tensor");
+  LX2V_REQUIRE(rows == 0 || (q && k && v && out), LX2V_EINVAL, "ulysses_pack: null tensor");
   LX2V_REQUIRE(world > 0 && dim > 0 && dim % (8 * world) == 0, LX2V_EINVAL, "ulysses_pack: dim=%d must be a multiple of 8*world (world=%d)", dim, world);
   LX2V_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0, LX2V_EINVAL, "ulysses_pack: row strides must be multiples of 8");
   LX2V_REQUIRE(lx2v_aligned16(q) && lx2v_aligned16(k) && lx2v_aligned16(v) && lx2v_aligned16(out), LX2V_EINVAL, "ulysses_pack: tensors must be 16-byte aligned");

@@ -200,7 +200,7 @@ extern "C" int lx2v_timestep_embedding_bf16(float t, int dim, uint16_t* out, voi
 }
 
 extern "C" int lx2v_silu_bf16(const uint16_t* x, uint16_t* out, int64_t n, void* stream) {
-  LX2V_REQUIRE(x && out, LX2V_EINVAL, "silu: null tensor");
+  LX2V_REQUIRE(n == 0 || (x && out), LX2V_EINVAL, "silu: null tensor");
   LX2V_REQUIRE(n >= 0, LX2V_EINVAL, "silu: n=%lld", (long long)n);
   if (n == 0) return LX2V_OK;
   hipLaunchKernelGGL(silu_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, out, n);
@@ -227,7 +227,7 @@ extern "C" int lx2v_lincomb_f32(float* out, int64_t n, int terms, const float* c
 }
 
 extern "C" int lx2v_cfg_combine_f32(float* out, const float* cond, const float* uncond, float guide_scale, int64_t n, void* stream) {
-  LX2V_REQUIRE(out && cond && uncond, LX2V_EINVAL, "cfg_combine: null tensor");
+  LX2V_REQUIRE(n == 0 || (out && cond && uncond), LX2V_EINVAL, "cfg_combine: null tensor");
   LX2V_REQUIRE(n >= 0 && n % 4 == 0, LX2V_EINVAL, "cfg_combine: n=%lld must be a multiple of 4", (long long)n);
   LX2V_REQUIRE(lx2v_aligned16(out) && lx2v_aligned16(cond) && lx2v_aligned16(uncond), LX2V_EINVAL, "cfg_combine: tensors must be 16-byte aligned");
   if (n == 0) return LX2V_OK;
@@ -237,7 +237,7 @@ extern "C" int lx2v_cfg_combine_f32(float* out, const float* cond, const float* 
 }
 
 extern "C" int lx2v_quant_fp8_rowwise(const uint16_t* x, int64_t ldx, uint8_t* out, int64_t ldo, float* scale, int64_t rows, int dim, void* stream) {
-  LX2V_REQUIRE(x && out && scale, LX2V_EINVAL, "quant_fp8: null tensor");
+  LX2V_REQUIRE(rows == 0 || (x && out && scale), LX2V_EINVAL, "quant_fp8: null tensor");
   LX2V_REQUIRE(rows >= 0 && dim > 0 && dim % 8 == 0, LX2V_EINVAL, "quant_fp8: dim=%d must be a positive multiple of 8", dim);
   LX2V_REQUIRE(ldx % 8 == 0 && ldo % 8 == 0 && ldx >= dim && ldo >= dim, LX2V_EINVAL, "quant_fp8: row strides must be multiples of 8 and >= dim");
   LX2V_REQUIRE(lx2v_aligned16(x) && (reinterpret_cast<uintptr_t>(out) & 7u) == 0, LX2V_EINVAL, "quant_fp8: x must be 16-byte, out 8-byte aligned");
@@ -253,7 +253,7 @@ extern "C" int lx2v_quant_fp8_rowwise(const uint16_t* x, int64_t ldx, uint8_t* o
 }
 
 extern "C" int lx2v_dequant_fp8_rowwise(const uint8_t* q, int64_t ldq, const float* scale, uint16_t* out, int64_t ldo, int64_t rows, int dim, void* stream) {
-  LX2V_REQUIRE(q && out && scale, LX2V_EINVAL, "dequant_fp8: null tensor");
+  LX2V_REQUIRE(rows == 0 || (q && out && scale), LX2V_EINVAL, "dequant_fp8: null tensor");
   LX2V_REQUIRE(rows >= 0 && dim > 0 && dim % 8 == 0, LX2V_EINVAL, "dequant_fp8: dim=%d must be a positive multiple of 8", dim);
   LX2V_REQUIRE(ldq % 8 == 0 && ldo % 8 == 0 && ldq >= dim && ldo >= dim, LX2V_EINVAL, "dequant_fp8: row strides must be multiples of 8 and >= dim");
   LX2V_REQUIRE(lx2v_aligned16(out) && (reinterpret_cast<uintptr_t>(q) & 7u) == 0, LX2V_EINVAL, "dequant_fp8: out must be 16-byte, q 8-byte aligned");

@@ -264,3 +264,25 @@ def test_ulysses_pack_layout(cuda):
     seg = dim // world
     exp = torch.stack([q, k, v], dim=1).view(rows, 3, world, seg).permute(2, 0, 1, 3)
     assert torch.equal(out, exp)
+
+
+def test_empty_inputs_are_no_ops(cuda):
+    """Zero rows / tokens: every entry point returns an empty result without launching anything
+    (a sequence-parallel rank can hold no text rows, a caller can pass an empty batch)."""
+    e = lambda *shape, dtype=torch.bfloat16: torch.empty(*shape, dtype=dtype, device=cuda)
+    w, b = _rand((64, 128), 1).to(cuda), torch.zeros(64, device=cuda)
+    assert hip.gemm(e(0, 128), w, b).shape == (0, 64)
+    assert hip.ln_modulate(e(0, 128)).shape == (0, 128)
+    assert hip.rmsnorm_rope(e(0, 128), torch.ones(128, device=cuda), None).shape == (0, 128)
+    assert hip.gate_residual_(e(0, 128), e(0, 128), None).shape == (0, 128)
+    assert hip.gelu_tanh(e(0, 128)).shape == (0, 128)
+    k = _rand((70, 2, 128), 2).to(cuda)
+    assert hip.attn_fwd(e(0, 2, 128), k, k).shape == (0, 256)
+    assert hip.attn_fwd_fp8(e(0, 2, 128), k, k).shape == (0, 256)
+    q8, sc = hip.quant_fp8_rowwise(e(0, 128))
+    assert q8.shape == (0, 128) and sc.shape == (0,)
+    assert hip.dequant_fp8_rowwise(q8, sc).shape == (0, 128)
+    w8, ws = hip.quant_fp8_rowwise(w)
+    assert hip.gemm_fp8(q8, sc, w8, ws, b).shape == (0, 64)
+    with pytest.raises(hip.Lx2vError):
+        hip.attn_fwd(_rand((4, 2, 128), 3).to(cuda), e(0, 2, 128), e(0, 2, 128))  # queries but no keys
