@@ -355,7 +355,8 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AttnParams p) 
 
 }  // namespace
 
-int lx2v_attn_launch_w4(const lx2v_attn::AttnParams& p, hipStream_t st);  // attn_fwd_w4.hip
+int lx2v_attn_launch_w4(const lx2v_attn::AttnParams& p, hipStream_t st);   // attn_fwd_w4.hip
+int lx2v_attn_launch_x16(const lx2v_attn::AttnParams& p, hipStream_t st);  // attn_fwd_x16.hip
 
 extern "C" int lx2v_attn_fwd_bf16(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk,
                                   const uint16_t* v, int64_t ldv, uint16_t* out, int64_t ldo,
@@ -387,16 +388,18 @@ extern "C" int lx2v_attn_fwd_bf16(const uint16_t* q, int64_t ldq, const uint16_t
   LX2V_REQUIRE((skv + 8 * KVB) * ldk * 2 < (1LL << 32) && (skv + 8 * KVB) * ldv * 2 < (1LL << 32), LX2V_EUNSUP,
                "attn_fwd: K/V extent (skv * token stride) must stay below 4 GiB for 32-bit buffer offsets");
   hipStream_t st = (hipStream_t)stream;
-  // Kernel choice: the 4-wave kernel (one wave per SIMD) unless RoPE is fused or
-  // LX2V_ATTN_KERNEL=w8 asks for the 8-wave one.
-  static const bool use_w4 = [] {
+  // Kernel choice: a one-wave-per-SIMD kernel unless RoPE is fused or LX2V_ATTN_KERNEL=w8 asks
+  // for the 8-wave one; LX2V_ATTN_KERNEL=x16 / w4 picks the MFMA shape (16x16x32 / 32x32x16).
+  static const int kernel = [] {
     const char* e = getenv("LX2V_ATTN_KERNEL");
-    return !(e && strcmp(e, "w8") == 0);
+    if (e && strcmp(e, "w8") == 0) return 8;
+    if (e && strcmp(e, "x16") == 0) return 16;
+    return 4;
   }();
-  if (rope_cos_sin == nullptr && use_w4) {
-    const int rc = lx2v_attn_launch_w4(p, st);
+  if (rope_cos_sin == nullptr && kernel != 8) {
+    const int rc = kernel == 16 ? lx2v_attn_launch_x16(p, st) : lx2v_attn_launch_w4(p, st);
     if (rc != LX2V_OK) return rc;
-    LX2V_CHECK_LAUNCH("attn_fwd(w4)");
+    LX2V_CHECK_LAUNCH("attn_fwd(one wave per SIMD)");
     return LX2V_OK;
   }
   // Tuning switch LX2V_ATTN_VARIANT (8-wave kernel): 0 = plain order, 1 (default) = pipelined K-fragment reads.

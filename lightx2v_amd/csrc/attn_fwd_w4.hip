@@ -32,7 +32,7 @@
 // DMA of K(t+4) and V(t+3) into their slots.  Three such groups stay in flight across each
 // barrier (counted vmcnt), i.e. every tile is requested three tiles before it is needed.
 // Rows past the last key come back as zeros from the buffer bounds check.
-#include "attn_common.h"
+#include "attn_w4_common.h"
 
 using namespace lx2v_attn;
 
@@ -62,50 +62,12 @@ LX2V_DEVICE void mfma_pv(f32x16& o, const u32x4& vf, const u32x4& pf) {
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o) : "v"(vf), "v"(pf));
 }
 
-// Round alignment.  Workgroup ids go to the 8 XCDs round-robin and, with one workgroup per CU,
-// run there in rounds of `cus_per_xcd`; the workgroups of one round share a head (or two) and
-// sweep its K/V together, so each tile is fetched into the XCD's L2 once per round -- as long as
-// they stay within the L2's reach of each other.  Left alone they drift apart over a few dozen
-// rounds (deep prefetch hides the misses that would hold a leader back) and every CU ends up
-// streaming K/V from memory on its own.  So a workgroup of round r waits, with a time limit, until
-// the XCD's previous round has finished.  Only a locality hint: any counter value is safe.
-struct RoundSync {
-  unsigned* done;   // [8] finished workgroups per XCD, zeroed before the launch; null = off
-  int cus_per_xcd;
-};
-constexpr long long kRoundWaitTicks = 10000;  // 100 us of the 100 MHz wall clock
-
-// The softmax VALU instructions are asm statements as well: their ORDER inside each MFMA gap is
-// part of the design (a lone wave issues in program order), and the compiler would otherwise hoist
-// exps above the MFMA they are meant to follow and gather the row-sum adds into one tree at the end
-// of the period.  None of them reads a register written by the statement just before it.
-LX2V_DEVICE float exp2_op(float x) {
-  float r;
-  asm volatile("v_exp_f32 %0, %1" : "=v"(r) : "v"(x));
-  return r;
-}
-LX2V_DEVICE void add_op(float& acc, float x) { asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(x)); }
-LX2V_DEVICE uint32_t cvt_pk_op(float lo, float hi) {
-  uint32_t r;
-  asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
-}
-
 // SHORT_KV only names a second symbol for short key sequences (cross-attention), so that kernel
 // profiles keep self- and cross-attention apart.
 template <bool SHORT_KV>
 __global__ __launch_bounds__(W4_THREADS) void attn_fwd_w4_kernel(const AttnParams p, const RoundSync rs) {
   __shared__ __attribute__((aligned(16))) char lds[2 * RING * KV_TILE_BYTES];
-  if (rs.done != nullptr) {
-    const unsigned round = (blockIdx.x >> 3) / rs.cus_per_xcd;
-    if (round > 0 && threadIdx.x == 0) {
-      const unsigned want = round * rs.cus_per_xcd;
-      const long long t_end = wall_clock64() + kRoundWaitTicks;
-      while (__hip_atomic_load(rs.done + (blockIdx.x & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && wall_clock64() < t_end)
-        __builtin_amdgcn_s_sleep(16);
-    }
-    __syncthreads();
-  }
+  round_enter(rs);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -446,7 +408,7 @@ __global__ __launch_bounds__(W4_THREADS) void attn_fwd_w4_kernel(const AttnParam
   // no DMA may still be writing this workgroup's LDS when it is handed to the next one
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 
-  if (rs.done != nullptr && threadIdx.x == 0) __hip_atomic_fetch_add(rs.done + (blockIdx.x & 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  round_leave(rs);
 
   // ---- normalise and store: o[b][db][i] = O[q0 + 32 b + r32][32 db + 8 (i>>2) + 4 h + (i&3)] ----
 #pragma unroll
@@ -469,37 +431,7 @@ __global__ __launch_bounds__(W4_THREADS) void attn_fwd_w4_kernel(const AttnParam
 
 }  // namespace
 
-namespace {
-__device__ __attribute__((aligned(64))) unsigned g_round_done[16];
-}
-
 // Launch for p already validated by lx2v_attn_fwd_bf16 (no RoPE; K/V extent + 8 tiles < 4 GiB).
 int lx2v_attn_launch_w4(const lx2v_attn::AttnParams& p, hipStream_t st) {
-  const int64_t nwg = (int64_t)p.nqb * p.heads;
-  RoundSync rs{nullptr, 32};
-  // Alignment pays when a head's K/V outgrows an XCD's L2 (4 MiB) and there are many rounds.
-  static const bool sync_off = [] { const char* e = getenv("LX2V_ATTN_ROUND_SYNC"); return e && atoi(e) == 0; }();
-  if (!sync_off && (int64_t)p.skv * HD * 4 > (8 << 20)) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { lx2v_set_error("attn_fwd(w4): hipGetDevice failed"); return LX2V_EHIP; }
-    static unsigned* counters[64];   // per device: address of that device's copy of g_round_done
-    static int cus[64];
-    if (counters[dev] == nullptr) {
-      hipDeviceProp_t prop;
-      if (hipGetSymbolAddress((void**)&counters[dev], HIP_SYMBOL(g_round_done)) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-        counters[dev] = nullptr;
-        lx2v_set_error("attn_fwd(w4): round counters unavailable");
-        return LX2V_EHIP;
-      }
-      cus[dev] = prop.multiProcessorCount / 8;
-    }
-    if (cus[dev] > 0 && nwg > 16 * (int64_t)cus[dev]) {
-      if (hipMemsetAsync(counters[dev], 0, 8 * sizeof(unsigned), st) != hipSuccess) { lx2v_set_error("attn_fwd(w4): counter reset failed"); return LX2V_EHIP; }
-      rs.done = counters[dev];
-      rs.cus_per_xcd = cus[dev];
-    }
-  }
-  if (p.skv <= 2048) hipLaunchKernelGGL(attn_fwd_w4_kernel<true>, dim3((unsigned)nwg), dim3(W4_THREADS), 0, st, p, rs);
-  else hipLaunchKernelGGL(attn_fwd_w4_kernel<false>, dim3((unsigned)nwg), dim3(W4_THREADS), 0, st, p, rs);
-  return LX2V_OK;
+  return launch_with_rounds(attn_fwd_w4_kernel<true>, attn_fwd_w4_kernel<false>, W4_THREADS, p, st, "attn_fwd(w4)");
 }

@@ -1,0 +1,447 @@
+// Attention forward, one wave per SIMD, on v_mfma_f32_16x16x32_bf16.
+//
+// Same structure as attn_fwd_w4.hip (4 waves x 64 query rows, half-tile software pipeline, K and
+// V rings filled by LDS-DMA, one barrier per tile, running maximum as accumulator init, overflow
+// check instead of a tracked maximum), re-tiled for the 16x16x32 instruction: back to back it
+// moves half the accumulator traffic of 32x32x16 per cycle, and under the chip's power limit the
+// same softmax filler stream beside it sustains about 13 % more FLOP/s.
+//
+// Per wave: four blocks of 16 query rows (qb).  A half tile of 32 keys is two key blocks (kb).
+//   QK(k): S[kb][qb] = K(kb) Q(qb)^T - m   2 kb x 4 k-steps of 32 channels x 4 qb = 32 MFMAs
+//   SM(k): exp2 / row sum / bf16 convert of the 32 scores a lane holds
+//   PV(k): O[qb][db] += V(db)^T P(qb)      8 blocks of 16 channels (db) x 4 qb = 32 MFMAs, the
+//          whole half tile being one contraction step
+// A step of the pipeline is one LDS fragment (a K fragment on even steps, a V^T fragment on odd
+// ones) and the four MFMAs (one per qb) that use it; a period has 16 steps = 64 MFMAs = 1024
+// MFMA cycles.  An MFMA of this shape holds vector issue for 8 of its 16 cycles, so each of the
+// four gaps of a step takes 8 cycles of other work: exp | add + convert | exp | add + LDS read.
+//
+// Operand maps (lane: c = lane & 15, g = lane >> 4).  A key block is NOT 16 consecutive keys: row
+// c of block kb is key 16 (c >> 3) + 8 ((c >> 2) & 1) + 4 kb + (c & 3) of the half tile, so that the
+// accumulators of lane group g are keys 8 g + 4 kb + i (i < 4), and the lane's eight probabilities
+// (kb = 0, 1) are keys 8 g .. 8 g + 7 in order: converted pairwise they ARE the B operand of PV
+// with the contraction in natural key order, and the V^T fragment is two transposed reads of
+// four consecutive keys whose two blocks per 32-lane half lie 8 rows apart (conflict-free on the
+// 8-row x 32-column sub-tiled V image).  The K image is swizzled by the MFMA row index c instead
+// of the key index, which keeps its ds_read_b128 conflict-free under that row permutation.
+#include "attn_w4_common.h"
+
+using namespace lx2v_attn;
+
+namespace {
+
+#ifndef X16_ABL
+#define X16_ABL 0  // timing ablations (results are wrong with any bit set): 1 softmax VALU, 2 fragment reads, 4 staging, 8 barrier, 16 overflow check, 32 K fragment reads, 64 V fragment reads, 128 exps (moves instead), 256 softmax VALU other than exps
+#endif
+constexpr int X16_THREADS = 256;
+constexpr int RING = 4;                        // tiles per LDS ring
+constexpr int K_RING = 0;                      // LDS byte offset of K slot 0
+constexpr int V_RING = RING * KV_TILE_BYTES;   // same for V
+constexpr float kRescaleSum = 64.0f;           // 2^kRescaleThr
+constexpr int DMA_PER_GROUP = 8;               // DMA instructions a wave issues per tile (4 K + 4 V)
+
+// D (VGPR) = A (VGPR: K rows) x B (AGPR: Q^T) + C (VGPR: -m broadcast)
+LX2V_DEVICE void mfma_qk_first(f32x4& s, const u32x4& kf, const u32x4& qf, const f32x4& negm) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(s) : "v"(kf), "a"(qf), "v"(negm));
+}
+// D (VGPR) += A (VGPR) x B (AGPR)
+LX2V_DEVICE void mfma_qk(f32x4& s, const u32x4& kf, const u32x4& qf) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(s) : "v"(kf), "a"(qf));
+}
+// D (AGPR) += A (VGPR: V^T) x B (VGPR: P)
+LX2V_DEVICE void mfma_pv(f32x4& o, const u32x4& vf, const u32x4& pf) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(o) : "v"(vf), "v"(pf));
+}
+
+// K image swizzle key of tile row `row`: the MFMA row index that reads it.
+LX2V_DEVICE int k_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2) | (((row >> 4) & 1) << 3); }
+
+// SHORT_KV only names a second symbol for short key sequences (cross-attention), so that kernel
+// profiles keep self- and cross-attention apart.
+template <bool SHORT_KV>
+__global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnParams p, const RoundSync rs) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * RING * KV_TILE_BYTES];
+  round_enter(rs);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int c16 = lane & 15, g = lane >> 4;
+
+  const int qb_wg = blockIdx.x % p.nqb;
+  const int head = blockIdx.x / p.nqb;
+  const int q0 = qb_wg * QROWS + wid * 64;  // block qb covers rows q0 + 16 qb .. +15
+
+  // ---- Q^T fragments, raw: lane holds Q[q0 + 16 qb + c][32 ks + 8 g .. +7] ----
+  u32x4 qraw[4][4];
+#pragma unroll
+  for (int qb = 0; qb < 4; ++qb) {
+    const int qrow_c = min(q0 + 16 * qb + c16, p.sq - 1);
+    const uint16_t* qp = p.q + (int64_t)qrow_c * p.ldq + head * HD + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qraw[qb][ks] = *reinterpret_cast<const u32x4*>(qp + ks * 32);
+  }
+
+  // ---- K/V staging by LDS-DMA: one wave instruction fills 1 KiB of a tile image, lane L the 16
+  // bytes at 16 L.  Wave w owns pieces j = w + 4 i (i < 4) of each tile.
+  //   K image: piece j = rows 4j..4j+3, lane = (row & 3, chunk position); position c holds chunk c ^ k_swz(row)
+  //   V image: piece j = rows 8 (j>>1) .. +7, d-blocks 2 (j&1), 2 (j&1) + 1; lane = (d-block & 1, row & 7, position)
+  // In both the i-dependence is "16 rows further", which goes into the scalar offset (and, for K,
+  // into bit 3 of the swizzle key).
+  const uint32_t wid_u = __builtin_amdgcn_readfirstlane(wid);
+  auto descriptor = [&](const uint16_t* base, int64_t bytes) __attribute__((always_inline)) -> u32x4 {
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    u32x4 d;
+    d[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    d[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));  // stride 0: raw buffer
+    d[2] = __builtin_amdgcn_readfirstlane((uint32_t)bytes);      // loads at or past it return 0
+    d[3] = 0x00020000u;
+    return d;
+  };
+  const u32x4 k_rs = descriptor(p.k + head * HD, (int64_t)p.skv * p.ldk * 2);
+  const u32x4 v_rs = descriptor(p.v + head * HD, (int64_t)p.skv * p.ldv * 2);
+  const int krow = 4 * wid + (lane >> 4);
+  const int vrow = 8 * (wid >> 1) + ((lane >> 2) & 7);
+  int k_vo[4], v_vo[4];  // piece i: 16 rows further
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    k_vo[i] = (int)((krow + 16 * i) * p.ldk * 2) + (((lane & 15) ^ k_swz(krow + 16 * i)) << 4);
+    v_vo[i] = (int)((vrow + 16 * i) * p.ldv * 2) + ((4 * (2 * (wid & 1) + (lane >> 5)) + ((lane & 3) ^ ((vrow >> 2) & 3))) << 4);
+  }
+  const uint32_t k_tile_bytes = (uint32_t)(KVB * p.ldk * 2), v_tile_bytes = (uint32_t)(KVB * p.ldv * 2);
+  const uint32_t dma_base = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)lds) + 1024 * wid_u;
+  // lane L of the wave: 16 bytes from base + voff + soff to LDS byte dma_base + DST + 16 L.  M0 is
+  // set by one add and not restored (nothing else in this kernel uses it).  The DMA is an asm
+  // statement: hipcc would drain vmcnt to 0 before every later LDS read if it knew an LDS write
+  // was in flight; completion is counted by hand at the tile barrier.
+  // Two statements so that the loop can put them into different MFMA gaps: M0 needs one wait
+  // state between its write and the DMA that reads it, which the instructions in between supply.
+  auto dma_m0 = [&](auto dstc) __attribute__((always_inline)) {
+    const uint32_t base = dma_base;
+    asm volatile("s_add_u32 m0, %0, %1" :: "s"(base), "i"(decltype(dstc)::value) : "memory", "scc");
+  };
+  auto dma_go = [&](const u32x4& rsrc, int voff, uint32_t soff) __attribute__((always_inline)) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  };
+  auto dma16 = [&](const u32x4& rsrc, int voff, uint32_t soff, auto dstc) __attribute__((always_inline)) {
+    dma_m0(dstc);
+    asm volatile("s_nop 0");
+    dma_go(rsrc, voff, soff);
+  };
+  auto dma_k = [&](int t, auto slotc, auto ic, uint32_t soff = 0) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    dma16(k_rs, k_vo[i], (uint32_t)t * k_tile_bytes + soff, IntC<K_RING + decltype(slotc)::value * KV_TILE_BYTES + 4096 * i>{});
+  };
+  auto dma_v = [&](int t, auto slotc, auto ic, uint32_t soff = 0) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    dma16(v_rs, v_vo[i], (uint32_t)t * v_tile_bytes + soff, IntC<V_RING + decltype(slotc)::value * KV_TILE_BYTES + 4096 * i>{});
+  };
+
+  // ---- fragment read offsets inside one tile image ----
+  // K (A operand of S^T), block kb of half tile hf: lane reads row 32 hf + 4 kb + krd_row, chunk
+  // 4 ks + g, stored at position (4 ks + g) ^ c.  hf and kb are immediates (8192 hf + 1024 kb).
+  const int krd_row = (c16 & 3) + 8 * ((c16 >> 2) & 1) + 16 * (c16 >> 3);
+  int k_rd[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) k_rd[ks] = krd_row * 256 + (((4 * ks + g) ^ c16) << 4);
+  // V^T (A operand of O^T), channel block db of half tile hf: per 16-lane group, lane 4 q4 + p4
+  // supplies row 32 hf + 8 g + 4 u + q4 (u = 0, 1: elements 0..3 / 4..7), channels 16 db + 4 p4 ..
+  // In the sub-tiled image that is 8192 hf + 2048 g + 512 (db >> 1) + 256 u + 64 q4 + 8 (p4 & 1)
+  //   + 16 (((p4 >> 1) ^ u) | (((db ^ g) & 1) << 1)): four lane bases [u][db & 1], the rest immediates.
+  const int q4 = c16 >> 2, p4 = c16 & 3;
+  int v_rd[2][2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int dp = 0; dp < 2; ++dp) {
+      v_rd[u][dp] = V_RING + 2048 * g + 256 * u + 64 * q4 + 8 * (p4 & 1) + 16 * (((p4 >> 1) ^ u) | (((dp ^ g) & 1) << 1));
+      asm volatile("" : "+v"(v_rd[u][dp]));  // ring base stays in the register: ds offsets are 16-bit
+    }
+  // Fragment of step s of a period.  Period parity PAR and the ring slot BUF = t % 4 of the
+  // period's tile t fix every buffer: even steps read K of half tile k+1 (k = 2t+PAR), m = s/2 =
+  // 4 kb + ks; odd steps the V^T fragment db = s/2 of half tile k-1.
+  auto frag_read_k = [&](auto parc, auto bufc, auto sc) __attribute__((always_inline)) -> u32x4 {
+    constexpr int PAR = decltype(parc)::value, BUF = decltype(bufc)::value, m = decltype(sc)::value >> 1;
+    constexpr int off = K_RING + (PAR == 0 ? BUF : (BUF + 1) % RING) * KV_TILE_BYTES + (PAR == 0 ? 8192 : 0) + 1024 * (m >> 2);
+    return *reinterpret_cast<const u32x4*>(lds + off + k_rd[m & 3]);
+  };
+  auto frag_read_v = [&](auto parc, auto bufc, auto sc, auto uc) __attribute__((always_inline)) -> bf16x4 {
+    constexpr int PAR = decltype(parc)::value, BUF = decltype(bufc)::value, db = decltype(sc)::value >> 1;
+    constexpr int off = (PAR == 0 ? (BUF + RING - 1) % RING : BUF) * KV_TILE_BYTES + (PAR == 0 ? 8192 : 0) + 512 * (db >> 1);  // + V_RING inside v_rd
+    return tr_read(lds + off + v_rd[decltype(uc)::value][db & 1]);
+  };
+  auto frag_read = [&](auto parc, auto bufc, auto sc) __attribute__((always_inline)) -> u32x4 {
+    if constexpr ((decltype(sc)::value & 1) == 0) {
+      return frag_read_k(parc, bufc, sc);
+    } else {
+      const bf16x4 lo = frag_read_v(parc, bufc, sc, IntC<0>{}), hi = frag_read_v(parc, bufc, sc, IntC<1>{});
+      return __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+  };
+
+  f32x4 o[4][8];    // accumulator file: o[qb][db][i] = O[q0 + 16 qb + c][16 db + 4 g + i]
+  f32x4 negm[4];    // -m of the lane's row of block qb in all 4 registers
+  u32x4 qf[4][4];   // c * Q^T fragments (accumulator file)
+  float l_run[4];
+  f32x4 s0[2][4], s1[2][4];   // [kb][qb]: scores of the even / odd half tiles
+  u32x4 pfa[4], pfb[4];       // [qb]: P of the even / odd half tiles
+  u32x4 ring[4];
+#pragma unroll
+  for (int qb = 0; qb < 4; ++qb) {
+    l_run[qb] = 0.f;
+    negm[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("" : "+v"(negm[qb]));
+#pragma unroll
+    for (int db = 0; db < 8; ++db) {
+      o[qb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+      asm volatile("" : "+a"(o[qb][db]));
+    }
+    pfa[qb] = pfb[qb] = u32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) s1[kb][qb] = f32x4{-1e30f, -1e30f, -1e30f, -1e30f};  // "half tile -1": every key masked
+  }
+
+  const int nt = (p.skv + KVB - 1) / KVB;
+
+  // S[kb][qb][i] of the half tile starting at key0 is key key0 + 8 g + 4 kb + i
+  auto mask_half = [&](f32x4 (&sv)[2][4], int key0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (key0 + 8 * g + 4 * kb + i >= p.skv) {
+#pragma unroll
+          for (int qb = 0; qb < 4; ++qb) sv[kb][qb][i] = -1e30f;
+        }
+  };
+
+  // Rare path, entered before any P of half tile k is used: move O, l, m, S(k) and the complete
+  // S(k+1) of block qb to the row maximum of S(k) (never downwards, except for half tile 0, whose
+  // maximum becomes m whatever its sign) and redo P(k).  MFMAs on these registers may have been
+  // issued a few cycles ago and others follow right after, hence the explicit wait states.
+  auto fixup = [&](auto qbc, f32x4 (&sc)[2][4], f32x4 (&sn)[2][4], u32x4& pc, bool first, float& ls) __attribute__((always_inline)) {
+    constexpr int qb = decltype(qbc)::value;
+    asm volatile("s_nop 7\n\ts_nop 7" : "+a"(o[qb][0]), "+a"(o[qb][1]), "+a"(o[qb][2]), "+a"(o[qb][3]), "+a"(o[qb][4]), "+a"(o[qb][5]), "+a"(o[qb][6]), "+a"(o[qb][7]),
+                 "+v"(sc[0][qb]), "+v"(sc[1][qb]), "+v"(sn[0][qb]), "+v"(sn[1][qb]));
+    float mxl = sc[0][qb][0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) mxl = fmaxf(mxl, sc[i >> 2][qb][i & 3]);
+    mxl = fmaxf(mxl, __shfl_xor(mxl, 16, 64));
+    const float mxc = fmaxf(mxl, __shfl_xor(mxl, 32, 64));
+    const float delta = first ? mxc : fmaxf(mxc, 0.f);
+    const float alpha = __builtin_amdgcn_exp2f(-delta);
+    l_run[qb] *= alpha;
+    static_for<0, 8>([&](auto dbc) __attribute__((always_inline)) {  // one tuple at a time through the architectural file
+      constexpr int db = decltype(dbc)::value;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[qb][db][i] *= alpha;
+      asm volatile("" : "+a"(o[qb][db]));
+    });
+    const float nm = negm[qb][0] - delta;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) negm[qb][i] = nm;
+    float e[8];
+    ls = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      sc[i >> 2][qb][i & 3] -= delta;
+      sn[i >> 2][qb][i & 3] -= delta;
+      e[i] = __builtin_amdgcn_exp2f(sc[i >> 2][qb][i & 3]);
+      ls += e[i];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pc[j] = pack2(e[2 * j], e[2 * j + 1]);
+    asm volatile("s_nop 1" : "+a"(o[qb][0]), "+a"(o[qb][1]), "+a"(o[qb][2]), "+a"(o[qb][3]), "+a"(o[qb][4]), "+a"(o[qb][5]), "+a"(o[qb][6]), "+a"(o[qb][7]),
+                 "+v"(negm[qb]), "+v"(pc), "+v"(sn[0][qb]), "+v"(sn[1][qb]));
+  };
+
+  // One period (k = 2t + PAR) of the pipeline.  Periods outside the real half tiles (k < 0 before
+  // the first tile, k >= 2 nt at the end) run the same code on zero tiles with every key masked.
+  auto period = [&](auto parc, auto bufc, int t) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(parc)::value, BUF = decltype(bufc)::value;
+    f32x4 (&Sc)[2][4] = PAR == 0 ? s0 : s1;     // S(k): exponentiated in this period
+    f32x4 (&Sn)[2][4] = PAR == 0 ? s1 : s0;     // S(k+1): accumulated in this period
+    u32x4 (&Pc)[4] = PAR == 0 ? pfa : pfb;      // P(k): produced
+    u32x4 (&Pp)[4] = PAR == 0 ? pfb : pfa;      // P(k-1): consumed
+    float ls[4] = {0.f, 0.f, 0.f, 0.f};
+    float ea[16], eb[16];  // exps of step s: pair s = (qb = s >> 2, j = s & 3) -> scores [j >> 1][qb][2 (j & 1)], +1
+    const int key0 = t * KVB + 32 * PAR;
+    if (key0 + 32 > p.skv) mask_half(Sc, key0);  // wave-uniform: only the last real half tile and the zero tiles
+    // DMA of this period: odd periods bring K(t+4) into the slot K(t) just left, even periods
+    // V(t+2) into the slot V(t-2) left at the previous barrier; four pieces each, on even steps:
+    // 0, 4, 8, 10 of the even periods (before their barrier, so that the count there is the same
+    // on every trip), 4, 8, 12, 14 of the odd ones (well after the barrier that released the slot).
+    const uint32_t dma_soff = __builtin_amdgcn_readfirstlane(PAR == 1 ? (uint32_t)(t + 4) * k_tile_bytes : (uint32_t)(t + 2) * v_tile_bytes);
+    bf16x4 vlo;
+    static_for<0, 16>([&](auto sc) __attribute__((always_inline)) {
+      constexpr int s = decltype(sc)::value, m = s >> 1;
+      constexpr int sq = s >> 2, sj = s & 3;                       // this step's softmax pair
+      constexpr int pq = (s - 1) >> 2, pj = (s - 1) & 3;           // the previous step's
+      constexpr int dma_i = PAR == 1 ? (s == 4 ? 0 : s == 8 ? 1 : s == 12 ? 2 : s == 14 ? 3 : -1) : (s == 0 ? 0 : s == 4 ? 1 : s == 8 ? 2 : s == 10 ? 3 : -1);
+      const u32x4 f = ring[s & 3];
+      auto mma = [&](auto qbc) __attribute__((always_inline)) {
+        constexpr int qb = decltype(qbc)::value;
+        if constexpr ((s & 1) == 0) {
+          if constexpr ((m & 3) == 0) mfma_qk_first(Sn[m >> 2][qb], f, qf[qb][0], negm[qb]);
+          else mfma_qk(Sn[m >> 2][qb], f, qf[qb][m & 3]);
+        } else {
+          mfma_pv(o[qb][m], f, Pp[qb]);
+        }
+      };
+      // ---- gap 0: first exp of this step's pair.  Its consumers run one step later, so that no
+      // instruction waits on a transcendental just issued. ----
+      mma(IntC<0>{});
+      if constexpr (dma_i >= 0 && !(X16_ABL & 4)) {
+        if constexpr (PAR == 1) dma_m0(IntC<K_RING + BUF * KV_TILE_BYTES + 4096 * dma_i>{});
+        else dma_m0(IntC<V_RING + ((BUF + 2) % RING) * KV_TILE_BYTES + 4096 * dma_i>{});
+      }
+      if constexpr (X16_ABL & 128) ea[s] = Sc[sj >> 1][sq][2 * (sj & 1)];
+      else if constexpr (!(X16_ABL & 1)) ea[s] = exp2_op(Sc[sj >> 1][sq][2 * (sj & 1)]);
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- gap 1: row sum and conversion of the previous pair; first V^T read or a DMA piece ----
+      mma(IntC<1>{});
+      if constexpr ((s & 1) == 1 && !(X16_ABL & (2 | 64))) {  // first of the two V^T reads of the fragment four steps on
+        if constexpr (s + 4 < 16) vlo = frag_read_v(parc, bufc, IntC<s + 4>{}, IntC<0>{});
+        else if constexpr (PAR == 0) vlo = frag_read_v(IntC<1>{}, bufc, IntC<s - 12>{}, IntC<0>{});
+        else vlo = frag_read_v(IntC<0>{}, IntC<(BUF + 1) % RING>{}, IntC<s - 12>{}, IntC<0>{});
+      }
+      if constexpr (dma_i >= 0 && !(X16_ABL & 4)) {
+        if constexpr (PAR == 1) dma_go(k_rs, k_vo[dma_i], dma_soff);
+        else dma_go(v_rs, v_vo[dma_i], dma_soff);
+      }
+      if constexpr (s > 0 && !(X16_ABL & (1 | 256))) {
+        add_op(ls[pq], ea[s - 1]);
+        Pc[pq][pj] = cvt_pk_op(ea[s - 1], eb[s - 1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- gap 2: second exp ----
+      mma(IntC<2>{});
+      if constexpr (X16_ABL & 128) eb[s] = Sc[sj >> 1][sq][2 * (sj & 1) + 1];
+      else if constexpr (!(X16_ABL & 1)) eb[s] = exp2_op(Sc[sj >> 1][sq][2 * (sj & 1) + 1]);
+      if constexpr (X16_ABL & 256) asm volatile("" :: "v"(ea[s]), "v"(eb[s]));
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- gap 3: second row-sum add; the fragment of step s + 4 replaces this step's ----
+      mma(IntC<3>{});
+      if constexpr ((X16_ABL & 2) || ((X16_ABL & 32) && (s & 1) == 0) || ((X16_ABL & 64) && (s & 1) == 1)) {
+        asm volatile("" : "+v"(ring[s & 3]));
+      } else if constexpr ((s & 1) == 0) {
+        if constexpr (s + 4 < 16) ring[s & 3] = frag_read_k(parc, bufc, IntC<s + 4>{});
+        else if constexpr (PAR == 0) ring[s & 3] = frag_read_k(IntC<1>{}, bufc, IntC<s - 12>{});
+        else ring[s & 3] = frag_read_k(IntC<0>{}, IntC<(BUF + 1) % RING>{}, IntC<s - 12>{});
+      } else {
+        bf16x4 vhi;
+        if constexpr (s + 4 < 16) vhi = frag_read_v(parc, bufc, IntC<s + 4>{}, IntC<1>{});
+        else if constexpr (PAR == 0) vhi = frag_read_v(IntC<1>{}, bufc, IntC<s - 12>{}, IntC<1>{});
+        else vhi = frag_read_v(IntC<0>{}, IntC<(BUF + 1) % RING>{}, IntC<s - 12>{}, IntC<1>{});
+        ring[s & 3] = __builtin_bit_cast(u32x4, __builtin_shufflevector(vlo, vhi, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+      if constexpr (s > 0 && !(X16_ABL & (1 | 256))) add_op(ls[pq], eb[s - 1]);
+      if constexpr (PAR == 0 && s == 11 && !(X16_ABL & 8)) {
+        // K(t+1) and V(t) (issued three tiles ago) have landed; after the barrier that holds for
+        // every wave.  This wave's last reads of K(t) and V(t-1) were issued before this point but
+        // are not waited for: an issued LDS read completes within ~10^2 cycles whatever its wave
+        // does next, while the first DMA into those slots is issued 8 steps (>= 512 cycles) after the
+        // barrier and lands an L2 latency later still.
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * DMA_PER_GROUP) & 15) | (((2 * DMA_PER_GROUP) >> 4) << 14));  // vmcnt(16)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    // ---- overflow check of half tile k, before any P(k) is used.  Every exp is positive, so a
+    // lane whose 8 exps of a row sum to at most 2^kRescaleThr holds no P above that bound: no row
+    // maximum is tracked in the loop, the rare path forms it. ----
+    if constexpr (!(X16_ABL & (1 | 256))) {  // consumers of the last step's exps
+      ls[3] += ea[15] + eb[15];
+      Pc[3][3] = pack2(ea[15], eb[15]);
+    }
+    asm volatile("" : "+v"(Pc[0]), "+v"(Pc[1]), "+v"(Pc[2]), "+v"(Pc[3]), "+v"(ls[0]), "+v"(ls[1]), "+v"(ls[2]), "+v"(ls[3]));
+    const bool first = PAR == 0 && t == 0;  // half tile 0: m becomes its true row maximum
+    if (!(X16_ABL & 16) && __builtin_expect(first || __any(fmaxf(fmaxf(ls[0], ls[1]), fmaxf(ls[2], ls[3])) > kRescaleSum), 0)) {
+      fixup(IntC<0>{}, Sc, Sn, Pc[0], first, ls[0]);
+      fixup(IntC<1>{}, Sc, Sn, Pc[1], first, ls[1]);
+      fixup(IntC<2>{}, Sc, Sn, Pc[2], first, ls[2]);
+      fixup(IntC<3>{}, Sc, Sn, Pc[3], first, ls[3]);
+    }
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) l_run[qb] += ls[qb];
+  };
+
+  // ---- prologue: Q fragments scaled and parked; DMA groups of tiles -4, -3, -2 (K0; K1, V0; K2,
+  // V1); V slot 3 zeroed by hand (it stands for V(-1): the two periods before half tile 0 multiply
+  // it by P = 0) ----
+#pragma unroll
+  for (int qb = 0; qb < 4; ++qb)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float f[8];
+      unpack8(qraw[qb][ks], f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] *= p.c;
+      qf[qb][ks] = pack8(f);
+      asm volatile("" : "+a"(qf[qb][ks]));
+    }
+  static_for<0, 4>([&](auto ic) __attribute__((always_inline)) {
+    *reinterpret_cast<u32x4*>(lds + V_RING + 3 * KV_TILE_BYTES + 4096 * decltype(ic)::value + tid * 16) = u32x4{0, 0, 0, 0};
+    dma_k(0, IntC<0>{}, ic);
+  });
+  static_for<0, 4>([&](auto ic) __attribute__((always_inline)) { dma_k(1, IntC<1>{}, ic); });
+  static_for<0, 4>([&](auto ic) __attribute__((always_inline)) { dma_v(0, IntC<0>{}, ic); });
+  static_for<0, 4>([&](auto ic) __attribute__((always_inline)) { dma_k(2, IntC<2>{}, ic); });
+  static_for<0, 4>([&](auto ic) __attribute__((always_inline)) { dma_v(1, IntC<1>{}, ic); });
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0x0070 | ((2 * DMA_PER_GROUP) & 15) | (((2 * DMA_PER_GROUP) >> 4) << 14));  // K0 landed (16 younger DMAs may fly), zeros written
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  // fragments of steps 0..3 of the first period run, (t = -1, odd), whose tile has ring slot 3
+  static_for<0, 4>([&](auto ic) __attribute__((always_inline)) { ring[decltype(ic)::value] = frag_read(IntC<1>{}, IntC<3>{}, ic); });
+
+  // Periods run in the fixed rotation (t-1, odd) (t, even) (t, odd) (t+1, even) ... over four
+  // tiles per trip, so that every LDS offset is static; the last period needed is (nt, even), which
+  // holds PV of the last half tile.
+  for (int t = 0;; t += 4) {
+    period(IntC<1>{}, IntC<3>{}, t - 1);
+    period(IntC<0>{}, IntC<0>{}, t);
+    if (t == nt) break;
+    period(IntC<1>{}, IntC<0>{}, t);
+    period(IntC<0>{}, IntC<1>{}, t + 1);
+    if (t + 1 == nt) break;
+    period(IntC<1>{}, IntC<1>{}, t + 1);
+    period(IntC<0>{}, IntC<2>{}, t + 2);
+    if (t + 2 == nt) break;
+    period(IntC<1>{}, IntC<2>{}, t + 2);
+    period(IntC<0>{}, IntC<3>{}, t + 3);
+    if (t + 3 == nt) break;
+  }
+  // no DMA may still be writing this workgroup's LDS when it is handed to the next one
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+
+  round_leave(rs);
+
+  // ---- normalise and store ----
+#pragma unroll
+  for (int qb = 0; qb < 4; ++qb) {
+    asm volatile("s_nop 7\n\ts_nop 7" : "+a"(o[qb][0]), "+a"(o[qb][1]), "+a"(o[qb][2]), "+a"(o[qb][3]), "+a"(o[qb][4]), "+a"(o[qb][5]), "+a"(o[qb][6]), "+a"(o[qb][7]));
+    float l = l_run[qb];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    const int qrow = q0 + 16 * qb + c16;
+    if (qrow < p.sq) {
+      uint16_t* op = p.out + (int64_t)qrow * p.ldo + head * HD + 4 * g;
+#pragma unroll
+      for (int db = 0; db < 8; ++db) {
+        u32x2 pk = {pack2(o[qb][db][0] * inv, o[qb][db][1] * inv), pack2(o[qb][db][2] * inv, o[qb][db][3] * inv)};
+        *reinterpret_cast<u32x2*>(op + 16 * db) = pk;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// Launch for p already validated by lx2v_attn_fwd_bf16 (no RoPE; K/V extent + 8 tiles < 4 GiB).
+int lx2v_attn_launch_x16(const lx2v_attn::AttnParams& p, hipStream_t st) {
+  return launch_with_rounds(attn_fwd_x16_kernel<true>, attn_fwd_x16_kernel<false>, X16_THREADS, p, st, "attn_fwd(x16)");
+}

@@ -1,0 +1,93 @@
+// Pieces shared by the one-wave-per-SIMD attention kernels (attn_fwd_w4.hip, attn_fwd_x16.hip):
+// the round alignment of workgroups on an XCD, the softmax VALU instructions as asm statements,
+// and the launch helper that owns the per-device round counters.
+#pragma once
+
+#include <stdlib.h>
+
+#include "attn_common.h"
+
+namespace {
+
+// Round alignment.  Workgroup ids go to the 8 XCDs round-robin and, with one workgroup per CU,
+// run there in rounds of `cus_per_xcd`; the workgroups of one round share a head (or two) and
+// sweep its K/V together, so each tile is fetched into the XCD's L2 once per round -- as long as
+// they stay within the L2's reach of each other.  Left alone they drift apart over a few dozen
+// rounds (deep prefetch hides the misses that would hold a leader back) and every CU ends up
+// streaming K/V from memory on its own.  So a workgroup of round r waits, with a time limit, until
+// the XCD's previous round has finished.  Only a locality hint: any counter value is safe.
+struct RoundSync {
+  unsigned* done;   // [8] finished workgroups per XCD, zeroed before the launch; null = off
+  int cus_per_xcd;
+};
+constexpr long long kRoundWaitTicks = 10000;  // 100 us of the 100 MHz wall clock
+
+// Entry of a workgroup: wait (bounded) for the XCD's previous round.  Ends in a workgroup barrier
+// when alignment is on.
+LX2V_DEVICE void round_enter(const RoundSync& rs) {
+  if (rs.done != nullptr) {
+    const unsigned round = (blockIdx.x >> 3) / rs.cus_per_xcd;
+    if (round > 0 && threadIdx.x == 0) {
+      const unsigned want = round * rs.cus_per_xcd;
+      const long long t_end = wall_clock64() + kRoundWaitTicks;
+      while (__hip_atomic_load(rs.done + (blockIdx.x & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && wall_clock64() < t_end)
+        __builtin_amdgcn_s_sleep(16);
+    }
+    __syncthreads();
+  }
+}
+LX2V_DEVICE void round_leave(const RoundSync& rs) {
+  if (rs.done != nullptr && threadIdx.x == 0) __hip_atomic_fetch_add(rs.done + (blockIdx.x & 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The softmax VALU instructions are asm statements: their ORDER inside each MFMA gap is part of
+// the design (a lone wave issues in program order), and the compiler would otherwise hoist exps
+// above the MFMA they are meant to follow and gather the row-sum adds into one tree at the end of
+// the period.  None of them reads a register written by the statement just before it.
+LX2V_DEVICE float exp2_op(float x) {
+  float r;
+  asm volatile("v_exp_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+LX2V_DEVICE void add_op(float& acc, float x) { asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(x)); }
+LX2V_DEVICE uint32_t cvt_pk_op(float lo, float hi) {
+  uint32_t r;
+  asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+__device__ __attribute__((aligned(64))) unsigned g_round_done[16];  // one copy per translation unit
+
+// Launch `kshort` (skv <= 2048) or `klong` over nqb * heads workgroups of `threads`, with round
+// alignment when a head's K/V outgrows an XCD's L2 (4 MiB) and there are many rounds.
+template <class KS, class KL>
+int launch_with_rounds(KS kshort, KL klong, int threads, const lx2v_attn::AttnParams& p, hipStream_t st, const char* what) {
+  const int64_t nwg = (int64_t)p.nqb * p.heads;
+  RoundSync rs{nullptr, 32};
+  static const bool sync_off = [] { const char* e = getenv("LX2V_ATTN_ROUND_SYNC"); return e && atoi(e) == 0; }();
+  if (!sync_off && (int64_t)p.skv * lx2v_attn::HD * 4 > (8 << 20)) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { lx2v_set_error("%s: hipGetDevice failed", what); return LX2V_EHIP; }
+    static unsigned* counters[64];   // per device: address of that device's copy of g_round_done
+    static int cus[64];
+    if (counters[dev] == nullptr) {
+      hipDeviceProp_t prop;
+      if (hipGetSymbolAddress((void**)&counters[dev], HIP_SYMBOL(g_round_done)) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        counters[dev] = nullptr;
+        lx2v_set_error("%s: round counters unavailable", what);
+        return LX2V_EHIP;
+      }
+      cus[dev] = prop.multiProcessorCount / 8;
+    }
+    if (cus[dev] > 0 && nwg > 16 * (int64_t)cus[dev]) {
+      if (hipMemsetAsync(counters[dev], 0, 8 * sizeof(unsigned), st) != hipSuccess) { lx2v_set_error("%s: counter reset failed", what); return LX2V_EHIP; }
+      rs.done = counters[dev];
+      rs.cus_per_xcd = cus[dev];
+    }
+  }
+  if (p.skv <= 2048) hipLaunchKernelGGL(kshort, dim3((unsigned)nwg), dim3(threads), 0, st, p, rs);
+  else hipLaunchKernelGGL(klong, dim3((unsigned)nwg), dim3(threads), 0, st, p, rs);
+  return LX2V_OK;
+}
+
+}  // namespace
