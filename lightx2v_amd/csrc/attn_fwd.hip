@@ -389,12 +389,14 @@ extern "C" int lx2v_attn_fwd_bf16(const uint16_t* q, int64_t ldq, const uint16_t
                "attn_fwd: K/V extent (skv * token stride) must stay below 4 GiB for 32-bit buffer offsets");
   hipStream_t st = (hipStream_t)stream;
   // Kernel choice: a one-wave-per-SIMD kernel unless RoPE is fused or LX2V_ATTN_KERNEL=w8 asks
-  // for the 8-wave one; LX2V_ATTN_KERNEL=x16 / w4 picks the MFMA shape (16x16x32 / 32x32x16).
+  // for the 8-wave one.  Of the two, the 16x16x32 kernel is the default (it needs more cycles than
+  // the 32x32x16 one but the chip holds a higher clock under it); LX2V_ATTN_KERNEL=w4 selects the
+  // 32x32x16 kernel.
   static const int kernel = [] {
     const char* e = getenv("LX2V_ATTN_KERNEL");
     if (e && strcmp(e, "w8") == 0) return 8;
-    if (e && strcmp(e, "x16") == 0) return 16;
-    return 4;
+    if (e && strcmp(e, "w4") == 0) return 4;
+    return 16;
   }();
   if (rope_cos_sin == nullptr && kernel != 8) {
     const int rc = kernel == 16 ? lx2v_attn_launch_x16(p, st) : lx2v_attn_launch_w4(p, st);

@@ -322,6 +322,9 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
       __builtin_amdgcn_sched_barrier(0);
       // ---- gap 3: second row-sum add; the fragment of step s + 4 replaces this step's ----
       mma(IntC<3>{});
+      // The next step's fragment is claimed here, so that the compiler's wait for it is issued in
+      // this MFMA's shadow instead of in front of the next one.
+      asm volatile("" :: "v"(ring[(s + 1) & 3]));
       if constexpr ((X16_ABL & 2) || ((X16_ABL & 32) && (s & 1) == 0) || ((X16_ABL & 64) && (s & 1) == 1)) {
         asm volatile("" : "+v"(ring[s & 3]));
       } else if constexpr ((s & 1) == 0) {
