@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out/gemm
 for lib in "$@"; do
   tag=$(basename $lib)
-  LD_LIBRARY_PATH=$lib timeout -s KILL 90 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/gemm/$tag -o p -- ./build/kernel_harness gemm1 75600 40 3 > gpurun_out/gemm/$tag.log 2>&1 || { echo "$tag failed"; exit 1; }
+  LD_LIBRARY_PATH=$lib timeout -s KILL 90 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/gemm/$tag -o p -- ./build/kernel_harness gemm1 75600 ${GEMM_H:-40} 3 > gpurun_out/gemm/$tag.log 2>&1 || { echo "$tag failed"; exit 1; }
   python3 - "$tag" gpurun_out/gemm/$tag <<'PY'
 import csv, glob, sys
 tag, d = sys.argv[1:3]
