@@ -392,12 +392,8 @@ extern "C" int lx2v_attn_fwd_bf16(const uint16_t* q, int64_t ldq, const uint16_t
   // for the 8-wave one.  Of the two, the 16x16x32 kernel is the default (it needs more cycles than
   // the 32x32x16 one but the chip holds a higher clock under it); LX2V_ATTN_KERNEL=w4 selects the
   // 32x32x16 kernel.
-  static const int kernel = [] {
-    const char* e = getenv("LX2V_ATTN_KERNEL");
-    if (e && strcmp(e, "w8") == 0) return 8;
-    if (e && strcmp(e, "w4") == 0) return 4;
-    return 16;
-  }();
+  const char* which = getenv("LX2V_ATTN_KERNEL");  // A/B switch, read per call
+  const int kernel = which == nullptr ? 16 : strcmp(which, "w8") == 0 ? 8 : strcmp(which, "w4") == 0 ? 4 : 16;
   if (rope_cos_sin == nullptr && kernel != 8) {
     const int rc = kernel == 16 ? lx2v_attn_launch_x16(p, st) : lx2v_attn_launch_w4(p, st);
     if (rc != LX2V_OK) return rc;

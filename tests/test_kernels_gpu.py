@@ -173,11 +173,20 @@ def test_gemm_k_segmented_operand(cuda):
     assert (out.float().cpu() - ref).abs().max().item() <= BF16_EPS * ref.abs().max().item() + 1e-3
 
 
+@pytest.fixture(params=["x16", "w4", "w8"])
+def attn_kernel(request, monkeypatch):
+    """Every attention kernel of the library behind the one C entry point: the default
+    (16x16x32 MFMAs, one wave per SIMD), the 32x32x16 one and the 8-wave one (the library reads
+    LX2V_ATTN_KERNEL on every call)."""
+    monkeypatch.setenv("LX2V_ATTN_KERNEL", request.param)
+    return request.param
+
+
 ATTN_SHAPES = [(64, 64, 1), (256, 64, 2), (100, 100, 1), (300, 520, 2), (257, 1, 1), (1, 257, 1), (1040, 1040, 3), (2000, 512, 2)]
 
 
 @pytest.mark.parametrize("sq,skv,H", ATTN_SHAPES)
-def test_attention_matches_sdpa(cuda, sq, skv, H):
+def test_attention_matches_sdpa(cuda, attn_kernel, sq, skv, H):
     q, k, v = _rand((sq, H, 128), 20), _rand((skv, H, 128), 21), _rand((skv, H, 128), 22)
     ref = R.sdpa(q.float(), k.float(), v.float())
     out = hip.attn_fwd(q.to(cuda), k.to(cuda), v.to(cuda))
@@ -188,7 +197,7 @@ def test_attention_matches_sdpa(cuda, sq, skv, H):
     assert (out.float().cpu() - ref).abs().max().item() <= 2e-2 * max(ref.abs().max().item(), 1.0)
 
 
-def test_attention_operand_layout_exact_integers(cuda):
+def test_attention_operand_layout_exact_integers(cuda, attn_kernel):
     """One-hot softmax (a single huge score per row) turns attention into a row gather of V with
     asymmetric integer data: any key/dim permutation mistake in the MFMA operand maps shows up."""
     S, H = 192, 2
@@ -206,7 +215,7 @@ def test_attention_operand_layout_exact_integers(cuda):
     assert (out.float().cpu() - ref).abs().max().item() <= 0.51  # bf16 rounding of |v| <= 99
 
 
-def test_attention_online_softmax_rescale_branch(cuda):
+def test_attention_online_softmax_rescale_branch(cuda, attn_kernel):
     """Spike one key per query block late in the sequence so the running maximum jumps at a chosen
     tile (forces the rescale path after many no-rescale tiles)."""
     S, H = 640, 1
@@ -222,7 +231,7 @@ def test_attention_online_softmax_rescale_branch(cuda):
 
 
 @pytest.mark.parametrize("sq,skv", [(300, 100), (256, 257), (300, 1000), (520, 2200)])
-def test_attention_never_consumes_memory_past_kv(cuda, sq, skv):
+def test_attention_never_consumes_memory_past_kv(cuda, attn_kernel, sq, skv):
     """K and V sit in the middle of one allocation whose every other element is NaN: the rows the
     kernel prefetches past the last key must come back as zeros, not as whatever follows the tensor."""
     H, pad = 1, 512
