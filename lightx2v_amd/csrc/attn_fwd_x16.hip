@@ -31,7 +31,7 @@ using namespace lx2v_attn;
 namespace {
 
 #ifndef X16_ABL
-#define X16_ABL 0  // timing ablations (results are wrong with any bit set): 1 softmax VALU, 2 fragment reads, 4 staging, 8 barrier, 16 overflow check, 32 K fragment reads, 64 V fragment reads, 128 exps (moves instead), 256 softmax VALU other than exps
+#define X16_ABL 0  // timing ablations (results are wrong with any bit set): 1 softmax VALU, 2 fragment reads, 4 staging, 8 barrier, 16 overflow check, 32 K fragment reads, 64 V fragment reads, 128 exps (moves instead), 256 softmax VALU other than exps, 512 K staging, 1024 V staging
 #endif
 constexpr int X16_THREADS = 256;
 constexpr int RING = 4;                        // tiles per LDS ring
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
       // ---- gap 0: first exp of this step's pair.  Its consumers run one step later, so that no
       // instruction waits on a transcendental just issued. ----
       mma(IntC<0>{});
-      if constexpr (dma_i >= 0 && !(X16_ABL & 4)) {
+      if constexpr (dma_i >= 0 && !(X16_ABL & 4) && !(X16_ABL & (PAR == 1 ? 512 : 1024))) {
         if constexpr (PAR == 1) dma_m0(IntC<K_RING + BUF * KV_TILE_BYTES + 4096 * dma_i>{});
         else dma_m0(IntC<V_RING + ((BUF + 2) % RING) * KV_TILE_BYTES + 4096 * dma_i>{});
       }
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
         else if constexpr (PAR == 0) vlo = frag_read_v(IntC<1>{}, bufc, IntC<s - 12>{}, IntC<0>{});
         else vlo = frag_read_v(IntC<0>{}, IntC<(BUF + 1) % RING>{}, IntC<s - 12>{}, IntC<0>{});
       }
-      if constexpr (dma_i >= 0 && !(X16_ABL & 4)) {
+      if constexpr (dma_i >= 0 && !(X16_ABL & 4) && !(X16_ABL & (PAR == 1 ? 512 : 1024))) {
         if constexpr (PAR == 1) dma_go(k_rs, k_vo[dma_i], dma_soff);
         else dma_go(v_rs, v_vo[dma_i], dma_soff);
       }
