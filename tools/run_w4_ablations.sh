@@ -4,6 +4,7 @@
 set -o pipefail
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out/abl
+export LX2V_ATTN_KERNEL=w4
 for m in "$@"; do
   lib=build/abl_$m; [ "$m" = 0 ] && lib=lightx2v_amd
   LD_LIBRARY_PATH=$lib timeout -s KILL 90 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/abl/m$m -o p -- ./build/kernel_harness selfattn 75600 40 2 > gpurun_out/abl/m$m.log 2>&1 || { echo "mask $m: run failed"; exit 1; }
