@@ -1,20 +1,23 @@
 // Attention forward, one wave per SIMD, on v_mfma_f32_16x16x32_bf16.
 //
-// Same structure as attn_fwd_w4.hip (4 waves x 64 query rows, half-tile software pipeline, K and
+// Same structure as attn_fwd_w4.hip (4 waves x 64 or 80 query rows, half-tile software pipeline, K and
 // V rings filled by LDS-DMA, one barrier per tile, running maximum as accumulator init, overflow
 // check instead of a tracked maximum), re-tiled for the 16x16x32 instruction: back to back it
 // moves half the accumulator traffic of 32x32x16 per cycle, and under the chip's power limit the
 // same softmax filler stream beside it sustains about 13 % more FLOP/s.
 //
-// Per wave: four blocks of 16 query rows (qb).  A half tile of 32 keys is two key blocks (kb).
-//   QK(k): S[kb][qb] = K(kb) Q(qb)^T - m   2 kb x 4 k-steps of 32 channels x 4 qb = 32 MFMAs
-//   SM(k): exp2 / row sum / bf16 convert of the 32 scores a lane holds
-//   PV(k): O[qb][db] += V(db)^T P(qb)      8 blocks of 16 channels (db) x 4 qb = 32 MFMAs, the
+// Per wave: NQB = 4 or 5 blocks of 16 query rows (qb).  A half tile of 32 keys is two key blocks (kb).
+//   QK(k): S[kb][qb] = K(kb) Q(qb)^T - m   2 kb x 4 k-steps of 32 channels x NQB = 8 NQB MFMAs
+//   SM(k): exp2 / row sum / bf16 convert of the 8 NQB scores a lane holds
+//   PV(k): O[qb][db] += V(db)^T P(qb)      8 blocks of 16 channels (db) x NQB = 8 NQB MFMAs, the
 //          whole half tile being one contraction step
 // A step of the pipeline is one LDS fragment (a K fragment on even steps, a V^T fragment on odd
-// ones) and the four MFMAs (one per qb) that use it; a period has 16 steps = 64 MFMAs = 1024
-// MFMA cycles.  An MFMA of this shape holds vector issue for 8 of its 16 cycles, so each of the
-// four gaps of a step takes 8 cycles of other work: exp | add + convert | exp | add + LDS read.
+// ones) and the NQB MFMAs (one per qb) that use it; a period has 16 steps = 16 NQB MFMAs.  An
+// MFMA of this shape holds vector issue for 8 of its 16 cycles, so each gap takes 8 cycles of
+// other work; the softmax of 4 NQB score pairs fills the 16 NQB gaps exactly, four gaps a pair:
+// exp | add + convert | exp | add.  With NQB = 5 (448 registers) a workgroup covers 320 query
+// rows, so K/V are streamed from L2 a fifth less often and every fragment read, DMA piece and
+// wait is shared by five MFMAs instead of four.
 //
 // Operand maps (lane: c = lane & 15, g = lane >> 4).  A key block is NOT 16 consecutive keys: row
 // c of block kb is key 16 (c >> 3) + 8 ((c >> 2) & 1) + 4 kb + (c & 3) of the half tile, so that the
@@ -58,7 +61,7 @@ LX2V_DEVICE int k_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2) | ((
 
 // SHORT_KV only names a second symbol for short key sequences (cross-attention), so that kernel
 // profiles keep self- and cross-attention apart.
-template <bool SHORT_KV>
+template <bool SHORT_KV, int NQB>
 __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnParams p, const RoundSync rs) {
   __shared__ __attribute__((aligned(16))) char lds[2 * RING * KV_TILE_BYTES];
   round_enter(rs);
@@ -70,12 +73,12 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
 
   const int qb_wg = blockIdx.x % p.nqb;
   const int head = blockIdx.x / p.nqb;
-  const int q0 = qb_wg * QROWS + wid * 64;  // block qb covers rows q0 + 16 qb .. +15
+  const int q0 = qb_wg * (64 * NQB) + wid * (16 * NQB);  // block qb covers rows q0 + 16 qb .. +15
 
   // ---- Q^T fragments, raw: lane holds Q[q0 + 16 qb + c][32 ks + 8 g .. +7] ----
-  u32x4 qraw[4][4];
+  u32x4 qraw[NQB][4];
 #pragma unroll
-  for (int qb = 0; qb < 4; ++qb) {
+  for (int qb = 0; qb < NQB; ++qb) {
     const int qrow_c = min(q0 + 16 * qb + c16, p.sq - 1);
     const uint16_t* qp = p.q + (int64_t)qrow_c * p.ldq + head * HD + g * 8;
 #pragma unroll
@@ -179,15 +182,15 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
     }
   };
 
-  f32x4 o[4][8];    // accumulator file: o[qb][db][i] = O[q0 + 16 qb + c][16 db + 4 g + i]
-  f32x4 negm[4];    // -m of the lane's row of block qb in all 4 registers
-  u32x4 qf[4][4];   // c * Q^T fragments (accumulator file)
-  float l_run[4];
-  f32x4 s0[2][4], s1[2][4];   // [kb][qb]: scores of the even / odd half tiles
-  u32x4 pfa[4], pfb[4];       // [qb]: P of the even / odd half tiles
+  f32x4 o[NQB][8];    // accumulator file: o[qb][db][i] = O[q0 + 16 qb + c][16 db + 4 g + i]
+  f32x4 negm[NQB];    // -m of the lane's row of block qb in all 4 registers
+  u32x4 qf[NQB][4];   // c * Q^T fragments (accumulator file)
+  float l_run[NQB];
+  f32x4 s0[2][NQB], s1[2][NQB];   // [kb][qb]: scores of the even / odd half tiles
+  u32x4 pfa[NQB], pfb[NQB];       // [qb]: P of the even / odd half tiles
   u32x4 ring[4];
 #pragma unroll
-  for (int qb = 0; qb < 4; ++qb) {
+  for (int qb = 0; qb < NQB; ++qb) {
     l_run[qb] = 0.f;
     negm[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
     asm volatile("" : "+v"(negm[qb]));
@@ -204,14 +207,14 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
   const int nt = (p.skv + KVB - 1) / KVB;
 
   // S[kb][qb][i] of the half tile starting at key0 is key key0 + 8 g + 4 kb + i
-  auto mask_half = [&](f32x4 (&sv)[2][4], int key0) __attribute__((always_inline)) {
+  auto mask_half = [&](f32x4 (&sv)[2][NQB], int key0) __attribute__((always_inline)) {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (key0 + 8 * g + 4 * kb + i >= p.skv) {
 #pragma unroll
-          for (int qb = 0; qb < 4; ++qb) sv[kb][qb][i] = -1e30f;
+          for (int qb = 0; qb < NQB; ++qb) sv[kb][qb][i] = -1e30f;
         }
   };
 
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
   // S(k+1) of block qb to the row maximum of S(k) (never downwards, except for half tile 0, whose
   // maximum becomes m whatever its sign) and redo P(k).  MFMAs on these registers may have been
   // issued a few cycles ago and others follow right after, hence the explicit wait states.
-  auto fixup = [&](auto qbc, f32x4 (&sc)[2][4], f32x4 (&sn)[2][4], u32x4& pc, bool first, float& ls) __attribute__((always_inline)) {
+  auto fixup = [&](auto qbc, f32x4 (&sc)[2][NQB], f32x4 (&sn)[2][NQB], u32x4& pc, bool first, float& ls) __attribute__((always_inline)) {
     constexpr int qb = decltype(qbc)::value;
     asm volatile("s_nop 7\n\ts_nop 7" : "+a"(o[qb][0]), "+a"(o[qb][1]), "+a"(o[qb][2]), "+a"(o[qb][3]), "+a"(o[qb][4]), "+a"(o[qb][5]), "+a"(o[qb][6]), "+a"(o[qb][7]),
                  "+v"(sc[0][qb]), "+v"(sc[1][qb]), "+v"(sn[0][qb]), "+v"(sn[1][qb]));
@@ -259,12 +262,15 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
   // the first tile, k >= 2 nt at the end) run the same code on zero tiles with every key masked.
   auto period = [&](auto parc, auto bufc, int t) __attribute__((always_inline)) {
     constexpr int PAR = decltype(parc)::value, BUF = decltype(bufc)::value;
-    f32x4 (&Sc)[2][4] = PAR == 0 ? s0 : s1;     // S(k): exponentiated in this period
-    f32x4 (&Sn)[2][4] = PAR == 0 ? s1 : s0;     // S(k+1): accumulated in this period
-    u32x4 (&Pc)[4] = PAR == 0 ? pfa : pfb;      // P(k): produced
-    u32x4 (&Pp)[4] = PAR == 0 ? pfb : pfa;      // P(k-1): consumed
-    float ls[4] = {0.f, 0.f, 0.f, 0.f};
-    float ea[16], eb[16];  // exps of step s: pair s = (qb = s >> 2, j = s & 3) -> scores [j >> 1][qb][2 (j & 1)], +1
+    f32x4 (&Sc)[2][NQB] = PAR == 0 ? s0 : s1;     // S(k): exponentiated in this period
+    f32x4 (&Sn)[2][NQB] = PAR == 0 ? s1 : s0;     // S(k+1): accumulated in this period
+    u32x4 (&Pc)[NQB] = PAR == 0 ? pfa : pfb;      // P(k): produced
+    u32x4 (&Pp)[NQB] = PAR == 0 ? pfb : pfa;      // P(k-1): consumed
+    constexpr int NPAIR = 4 * NQB;  // softmax pairs per period; a period has 16 NQB = 4 NPAIR gaps
+    float ls[NQB];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) ls[qb] = 0.f;
+    float ea[NPAIR], eb[NPAIR];  // exps of pair p = (qb = p >> 2, j = p & 3): scores [j >> 1][qb][2 (j & 1)], + 1
     const int key0 = t * KVB + 32 * PAR;
     if (key0 + 32 > p.skv) mask_half(Sc, key0);  // wave-uniform: only the last real half tile and the zero tiles
     // DMA of this period: odd periods bring K(t+4) into the slot K(t) just left, even periods
@@ -275,107 +281,114 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
     bf16x4 vlo;
     static_for<0, 16>([&](auto sc) __attribute__((always_inline)) {
       constexpr int s = decltype(sc)::value, m = s >> 1;
-      constexpr int sq = s >> 2, sj = s & 3;                       // this step's softmax pair
-      constexpr int pq = (s - 1) >> 2, pj = (s - 1) & 3;           // the previous step's
       constexpr int dma_i = PAR == 1 ? (s == 4 ? 0 : s == 8 ? 1 : s == 12 ? 2 : s == 14 ? 3 : -1) : (s == 0 ? 0 : s == 4 ? 1 : s == 8 ? 2 : s == 10 ? 3 : -1);
+      constexpr bool DMA = dma_i >= 0 && !(X16_ABL & 4) && !(X16_ABL & (PAR == 1 ? 512 : 1024));
       const u32x4 f = ring[s & 3];
-      auto mma = [&](auto qbc) __attribute__((always_inline)) {
-        constexpr int qb = decltype(qbc)::value;
+      // One gap per query block: the MFMA, then what is not VALU work (it issues in the MFMA's
+      // shadow), then the gap's share of the softmax.  Gap G = NQB s + qb of the period carries
+      // phase G & 3 of pair G >> 2:  0 first exp | 1 row-sum add and conversion of the previous
+      // pair | 2 second exp | 3 second add of the previous pair.  Consumers run a pair behind their
+      // exps, so that no instruction waits on a transcendental just issued.
+      static_for<0, NQB>([&](auto qbc) __attribute__((always_inline)) {
+        constexpr int qb = decltype(qbc)::value, G = NQB * s + qb, pr = G >> 2, ph = G & 3;
+        constexpr int sq = pr >> 2, sj = pr & 3, pq = (pr - 1) >> 2, pj = (pr - 1) & 3;
         if constexpr ((s & 1) == 0) {
           if constexpr ((m & 3) == 0) mfma_qk_first(Sn[m >> 2][qb], f, qf[qb][0], negm[qb]);
           else mfma_qk(Sn[m >> 2][qb], f, qf[qb][m & 3]);
         } else {
           mfma_pv(o[qb][m], f, Pp[qb]);
         }
-      };
-      // ---- gap 0: first exp of this step's pair.  Its consumers run one step later, so that no
-      // instruction waits on a transcendental just issued. ----
-      mma(IntC<0>{});
-      if constexpr (dma_i >= 0 && !(X16_ABL & 4) && !(X16_ABL & (PAR == 1 ? 512 : 1024))) {
-        if constexpr (PAR == 1) dma_m0(IntC<K_RING + BUF * KV_TILE_BYTES + 4096 * dma_i>{});
-        else dma_m0(IntC<V_RING + ((BUF + 2) % RING) * KV_TILE_BYTES + 4096 * dma_i>{});
-      }
-      if constexpr (X16_ABL & 128) ea[s] = Sc[sj >> 1][sq][2 * (sj & 1)];
-      else if constexpr (!(X16_ABL & 1)) ea[s] = exp2_op(Sc[sj >> 1][sq][2 * (sj & 1)]);
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- gap 1: row sum and conversion of the previous pair; first V^T read or a DMA piece ----
-      mma(IntC<1>{});
-      if constexpr ((s & 1) == 1 && !(X16_ABL & (2 | 64))) {  // first of the two V^T reads of the fragment four steps on
-        if constexpr (s + 4 < 16) vlo = frag_read_v(parc, bufc, IntC<s + 4>{}, IntC<0>{});
-        else if constexpr (PAR == 0) vlo = frag_read_v(IntC<1>{}, bufc, IntC<s - 12>{}, IntC<0>{});
-        else vlo = frag_read_v(IntC<0>{}, IntC<(BUF + 1) % RING>{}, IntC<s - 12>{}, IntC<0>{});
-      }
-      if constexpr (dma_i >= 0 && !(X16_ABL & 4) && !(X16_ABL & (PAR == 1 ? 512 : 1024))) {
-        if constexpr (PAR == 1) dma_go(k_rs, k_vo[dma_i], dma_soff);
-        else dma_go(v_rs, v_vo[dma_i], dma_soff);
-      }
-      if constexpr (s > 0 && !(X16_ABL & (1 | 256))) {
-        add_op(ls[pq], ea[s - 1]);
-        Pc[pq][pj] = cvt_pk_op(ea[s - 1], eb[s - 1]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- gap 2: second exp ----
-      mma(IntC<2>{});
-      if constexpr (X16_ABL & 128) eb[s] = Sc[sj >> 1][sq][2 * (sj & 1) + 1];
-      else if constexpr (!(X16_ABL & 1)) eb[s] = exp2_op(Sc[sj >> 1][sq][2 * (sj & 1) + 1]);
-      if constexpr (X16_ABL & 256) asm volatile("" :: "v"(ea[s]), "v"(eb[s]));
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- gap 3: second row-sum add; the fragment of step s + 4 replaces this step's ----
-      mma(IntC<3>{});
-      // The next step's fragment is claimed here, so that the compiler's wait for it is issued in
-      // this MFMA's shadow instead of in front of the next one.
-      asm volatile("" :: "v"(ring[(s + 1) & 3]));
-      if constexpr ((X16_ABL & 2) || ((X16_ABL & 32) && (s & 1) == 0) || ((X16_ABL & 64) && (s & 1) == 1)) {
-        asm volatile("" : "+v"(ring[s & 3]));
-      } else if constexpr ((s & 1) == 0) {
-        if constexpr (s + 4 < 16) ring[s & 3] = frag_read_k(parc, bufc, IntC<s + 4>{});
-        else if constexpr (PAR == 0) ring[s & 3] = frag_read_k(IntC<1>{}, bufc, IntC<s - 12>{});
-        else ring[s & 3] = frag_read_k(IntC<0>{}, IntC<(BUF + 1) % RING>{}, IntC<s - 12>{});
-      } else {
-        bf16x4 vhi;
-        if constexpr (s + 4 < 16) vhi = frag_read_v(parc, bufc, IntC<s + 4>{}, IntC<1>{});
-        else if constexpr (PAR == 0) vhi = frag_read_v(IntC<1>{}, bufc, IntC<s - 12>{}, IntC<1>{});
-        else vhi = frag_read_v(IntC<0>{}, IntC<(BUF + 1) % RING>{}, IntC<s - 12>{}, IntC<1>{});
-        ring[s & 3] = __builtin_bit_cast(u32x4, __builtin_shufflevector(vlo, vhi, 0, 1, 2, 3, 4, 5, 6, 7));
-      }
-      if constexpr (s > 0 && !(X16_ABL & (1 | 256))) add_op(ls[pq], eb[s - 1]);
-      if constexpr (PAR == 0 && s == 11 && !(X16_ABL & 8)) {
-        // K(t+1) and V(t) (issued three tiles ago) have landed; after the barrier that holds for
-        // every wave.  This wave's last reads of K(t) and V(t-1) were issued before this point but
-        // are not waited for: an issued LDS read completes within ~10^2 cycles whatever its wave
-        // does next, while the first DMA into those slots is issued 8 steps (>= 512 cycles) after the
-        // barrier and lands an L2 latency later still.
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * DMA_PER_GROUP) & 15) | (((2 * DMA_PER_GROUP) >> 4) << 14));  // vmcnt(16)
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-      }
-      __builtin_amdgcn_sched_barrier(0);
+        if constexpr (qb == 0 && DMA) {
+          if constexpr (PAR == 1) dma_m0(IntC<K_RING + BUF * KV_TILE_BYTES + 4096 * dma_i>{});
+          else dma_m0(IntC<V_RING + ((BUF + 2) % RING) * KV_TILE_BYTES + 4096 * dma_i>{});
+        }
+        if constexpr (qb == 1) {
+          if constexpr ((s & 1) == 1 && !(X16_ABL & (2 | 64))) {  // first of the two V^T reads of the fragment four steps on
+            if constexpr (s + 4 < 16) vlo = frag_read_v(parc, bufc, IntC<s + 4>{}, IntC<0>{});
+            else if constexpr (PAR == 0) vlo = frag_read_v(IntC<1>{}, bufc, IntC<s - 12>{}, IntC<0>{});
+            else vlo = frag_read_v(IntC<0>{}, IntC<(BUF + 1) % RING>{}, IntC<s - 12>{}, IntC<0>{});
+          }
+          if constexpr (DMA) {
+            if constexpr (PAR == 1) dma_go(k_rs, k_vo[dma_i], dma_soff);
+            else dma_go(v_rs, v_vo[dma_i], dma_soff);
+          }
+        }
+        if constexpr (qb == NQB - 1) {
+          // The next step's fragment is claimed here, so that the compiler's wait for it is issued
+          // in this MFMA's shadow instead of in front of the next one; then the fragment of step
+          // s + 4 replaces this step's.
+          asm volatile("" :: "v"(ring[(s + 1) & 3]));
+          if constexpr ((X16_ABL & 2) || ((X16_ABL & 32) && (s & 1) == 0) || ((X16_ABL & 64) && (s & 1) == 1)) {
+            asm volatile("" : "+v"(ring[s & 3]));
+          } else if constexpr ((s & 1) == 0) {
+            if constexpr (s + 4 < 16) ring[s & 3] = frag_read_k(parc, bufc, IntC<s + 4>{});
+            else if constexpr (PAR == 0) ring[s & 3] = frag_read_k(IntC<1>{}, bufc, IntC<s - 12>{});
+            else ring[s & 3] = frag_read_k(IntC<0>{}, IntC<(BUF + 1) % RING>{}, IntC<s - 12>{});
+          } else {
+            bf16x4 vhi;
+            if constexpr (s + 4 < 16) vhi = frag_read_v(parc, bufc, IntC<s + 4>{}, IntC<1>{});
+            else if constexpr (PAR == 0) vhi = frag_read_v(IntC<1>{}, bufc, IntC<s - 12>{}, IntC<1>{});
+            else vhi = frag_read_v(IntC<0>{}, IntC<(BUF + 1) % RING>{}, IntC<s - 12>{}, IntC<1>{});
+            ring[s & 3] = __builtin_bit_cast(u32x4, __builtin_shufflevector(vlo, vhi, 0, 1, 2, 3, 4, 5, 6, 7));
+          }
+        }
+        if constexpr (!(X16_ABL & 1)) {
+          if constexpr (ph == 0) {
+            if constexpr (X16_ABL & 128) ea[pr] = Sc[sj >> 1][sq][2 * (sj & 1)];
+            else ea[pr] = exp2_op(Sc[sj >> 1][sq][2 * (sj & 1)]);
+          } else if constexpr (ph == 2) {
+            if constexpr (X16_ABL & 128) eb[pr] = Sc[sj >> 1][sq][2 * (sj & 1) + 1];
+            else eb[pr] = exp2_op(Sc[sj >> 1][sq][2 * (sj & 1) + 1]);
+            if constexpr (X16_ABL & 256) asm volatile("" :: "v"(ea[pr]), "v"(eb[pr]));
+          } else if constexpr (pr > 0 && !(X16_ABL & 256)) {
+            if constexpr (ph == 1) {
+              add_op(ls[pq], ea[pr - 1]);
+              Pc[pq][pj] = cvt_pk_op(ea[pr - 1], eb[pr - 1]);
+            } else {
+              add_op(ls[pq], eb[pr - 1]);
+            }
+          }
+        }
+        // Tile barrier: K(t+1) and V(t) (issued three tiles ago) have landed; after the barrier that
+        // holds for every wave.  This wave's last reads of K(t) and V(t-1) were issued before this
+        // point but are not waited for: an issued LDS read completes within ~10^2 cycles whatever
+        // its wave does next, while the first DMA into those slots is issued 8 steps (>= 512 cycles)
+        // after the barrier and lands an L2 latency later still.
+        if constexpr (qb == NQB - 1 && PAR == 0 && s == 11 && !(X16_ABL & 8)) {
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * DMA_PER_GROUP) & 15) | (((2 * DMA_PER_GROUP) >> 4) << 14));  // vmcnt(16)
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
     });
     // ---- overflow check of half tile k, before any P(k) is used.  Every exp is positive, so a
     // lane whose 8 exps of a row sum to at most 2^kRescaleThr holds no P above that bound: no row
     // maximum is tracked in the loop, the rare path forms it. ----
-    if constexpr (!(X16_ABL & (1 | 256))) {  // consumers of the last step's exps
-      ls[3] += ea[15] + eb[15];
-      Pc[3][3] = pack2(ea[15], eb[15]);
+    if constexpr (!(X16_ABL & (1 | 256))) {  // consumers of the last pair's exps
+      ls[NQB - 1] += ea[NPAIR - 1] + eb[NPAIR - 1];
+      Pc[NQB - 1][3] = pack2(ea[NPAIR - 1], eb[NPAIR - 1]);
     }
-    asm volatile("" : "+v"(Pc[0]), "+v"(Pc[1]), "+v"(Pc[2]), "+v"(Pc[3]), "+v"(ls[0]), "+v"(ls[1]), "+v"(ls[2]), "+v"(ls[3]));
+    float lmax = 0.f;
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+      asm volatile("" : "+v"(Pc[qb]), "+v"(ls[qb]));
+      lmax = fmaxf(lmax, ls[qb]);
+    }
     const bool first = PAR == 0 && t == 0;  // half tile 0: m becomes its true row maximum
-    if (!(X16_ABL & 16) && __builtin_expect(first || __any(fmaxf(fmaxf(ls[0], ls[1]), fmaxf(ls[2], ls[3])) > kRescaleSum), 0)) {
-      fixup(IntC<0>{}, Sc, Sn, Pc[0], first, ls[0]);
-      fixup(IntC<1>{}, Sc, Sn, Pc[1], first, ls[1]);
-      fixup(IntC<2>{}, Sc, Sn, Pc[2], first, ls[2]);
-      fixup(IntC<3>{}, Sc, Sn, Pc[3], first, ls[3]);
+    if (!(X16_ABL & 16) && __builtin_expect(first || __any(lmax > kRescaleSum), 0)) {
+      static_for<0, NQB>([&](auto qbc) __attribute__((always_inline)) { fixup(qbc, Sc, Sn, Pc[decltype(qbc)::value], first, ls[decltype(qbc)::value]); });
     }
 #pragma unroll
-    for (int qb = 0; qb < 4; ++qb) l_run[qb] += ls[qb];
+    for (int qb = 0; qb < NQB; ++qb) l_run[qb] += ls[qb];
   };
 
   // ---- prologue: Q fragments scaled and parked; DMA groups of tiles -4, -3, -2 (K0; K1, V0; K2,
   // V1); V slot 3 zeroed by hand (it stands for V(-1): the two periods before half tile 0 multiply
   // it by P = 0) ----
 #pragma unroll
-  for (int qb = 0; qb < 4; ++qb)
+  for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       float f[8];
@@ -424,7 +437,7 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
 
   // ---- normalise and store ----
 #pragma unroll
-  for (int qb = 0; qb < 4; ++qb) {
+  for (int qb = 0; qb < NQB; ++qb) {
     asm volatile("s_nop 7\n\ts_nop 7" : "+a"(o[qb][0]), "+a"(o[qb][1]), "+a"(o[qb][2]), "+a"(o[qb][3]), "+a"(o[qb][4]), "+a"(o[qb][5]), "+a"(o[qb][6]), "+a"(o[qb][7]));
     float l = l_run[qb];
     l += __shfl_xor(l, 16, 64);
@@ -445,6 +458,26 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
 }  // namespace
 
 // Launch for p already validated by lx2v_attn_fwd_bf16 (no RoPE; K/V extent + 8 tiles < 4 GiB).
+// Query rows per workgroup = 4 waves x 16 NQB.  Five blocks per wave stream K/V a fifth less often
+// and measure about 4 % faster per row, but workgroups run in rounds of one per CU and a round
+// costs in proportion to NQB, so the choice goes by rounds x NQB (14B/720p: 47 x 4 against
+// 38 x 5 x 0.96; 1.3B/480p: 6 x 4 against 5 x 5 x 0.96).  LX2V_ATTN_QB=4|5 overrides it (A/B
+// switch, read per call).
 int lx2v_attn_launch_x16(const lx2v_attn::AttnParams& p, hipStream_t st) {
-  return launch_with_rounds(attn_fwd_x16_kernel<true>, attn_fwd_x16_kernel<false>, X16_THREADS, p, st, "attn_fwd(x16)");
+  static int cus_cached[64];
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+    if (cus_cached[dev] == 0) {
+      int v = 0;
+      cus_cached[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    cus = cus_cached[dev];
+  }
+  auto rounds = [&](int nqb_wave) { return ((int64_t)((p.sq + 64 * nqb_wave - 1) / (64 * nqb_wave)) * p.heads + cus - 1) / cus; };
+  int nqb_wave = (double)rounds(5) * 5 * 0.96 < (double)rounds(4) * 4 ? 5 : 4;
+  if (const char* e = getenv("LX2V_ATTN_QB")) nqb_wave = atoi(e) == 5 ? 5 : 4;
+  lx2v_attn::AttnParams pp = p;
+  pp.nqb = (p.sq + 64 * nqb_wave - 1) / (64 * nqb_wave);
+  if (nqb_wave == 5) return launch_with_rounds(attn_fwd_x16_kernel<true, 5>, attn_fwd_x16_kernel<false, 5>, X16_THREADS, pp, st, "attn_fwd(x16)");
+  return launch_with_rounds(attn_fwd_x16_kernel<true, 4>, attn_fwd_x16_kernel<false, 4>, X16_THREADS, pp, st, "attn_fwd(x16)");
 }

@@ -173,12 +173,15 @@ def test_gemm_k_segmented_operand(cuda):
     assert (out.float().cpu() - ref).abs().max().item() <= BF16_EPS * ref.abs().max().item() + 1e-3
 
 
-@pytest.fixture(params=["x16", "w4", "w8"])
+@pytest.fixture(params=["x16-4", "x16-5", "w4", "w8"])
 def attn_kernel(request, monkeypatch):
-    """Every attention kernel of the library behind the one C entry point: the default
-    (16x16x32 MFMAs, one wave per SIMD), the 32x32x16 one and the 8-wave one (the library reads
-    LX2V_ATTN_KERNEL on every call)."""
-    monkeypatch.setenv("LX2V_ATTN_KERNEL", request.param)
+    """Every attention kernel of the library behind the one C entry point: the 16x16x32-MFMA
+    kernel (one wave per SIMD) with 4 and with 5 query blocks per wave, the 32x32x16 one and the
+    8-wave one (the library reads LX2V_ATTN_KERNEL and LX2V_ATTN_QB on every call)."""
+    name, _, qb = request.param.partition("-")
+    monkeypatch.setenv("LX2V_ATTN_KERNEL", name)
+    if qb:
+        monkeypatch.setenv("LX2V_ATTN_QB", qb)
     return request.param
 
 
