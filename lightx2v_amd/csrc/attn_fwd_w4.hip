@@ -433,5 +433,5 @@ __global__ __launch_bounds__(W4_THREADS) void attn_fwd_w4_kernel(const AttnParam
 
 // Launch for p already validated by lx2v_attn_fwd_bf16 (no RoPE; K/V extent + 8 tiles < 4 GiB).
 int lx2v_attn_launch_w4(const lx2v_attn::AttnParams& p, hipStream_t st) {
-  return launch_with_rounds(attn_fwd_w4_kernel<true>, attn_fwd_w4_kernel<false>, W4_THREADS, p, st, "attn_fwd(w4)");
+  return launch_with_rounds(attn_fwd_w4_kernel<true>, attn_fwd_w4_kernel<false>, W4_THREADS, p, (int64_t)p.nqb * p.heads, st, "attn_fwd(w4)");
 }

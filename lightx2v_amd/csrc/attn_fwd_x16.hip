@@ -302,7 +302,7 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
           if constexpr (PAR == 1) dma_m0(IntC<K_RING + BUF * KV_TILE_BYTES + 4096 * dma_i>{});
           else dma_m0(IntC<V_RING + ((BUF + 2) % RING) * KV_TILE_BYTES + 4096 * dma_i>{});
         }
-        if constexpr (qb == 1) {
+        if constexpr (qb == (NQB > 1 ? 1 : 0)) {
           if constexpr ((s & 1) == 1 && !(X16_ABL & (2 | 64))) {  // first of the two V^T reads of the fragment four steps on
             if constexpr (s + 4 < 16) vlo = frag_read_v(parc, bufc, IntC<s + 4>{}, IntC<0>{});
             else if constexpr (PAR == 0) vlo = frag_read_v(IntC<1>{}, bufc, IntC<s - 12>{}, IntC<0>{});
@@ -461,8 +461,13 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
 // Query rows per workgroup = 4 waves x 16 NQB.  Five blocks per wave stream K/V a fifth less often
 // and measure about 4 % faster per row, but workgroups run in rounds of one per CU and a round
 // costs in proportion to NQB, so the choice goes by rounds x NQB (14B/720p: 47 x 4 against
-// 38 x 5 x 0.96; 1.3B/480p: 6 x 4 against 5 x 5 x 0.96).  LX2V_ATTN_QB=4|5 overrides it (A/B
-// switch, read per call).
+// 38 x 5 x 0.96; 1.3B/480p: 6 x 4 against 5 x 5 x 0.96).  When the last round would hold only a few
+// workgroups, all of the last head, the main launch stops at the last full round and the
+// remaining query rows go to a second launch with one block per wave (64 rows per workgroup:
+// more, much shorter workgroups instead of a nearly empty full-length round; 14B/720p: 8 workgroups
+// of 320 rows become 37 of 64, 77.4 -> 76.1 ms per launch).
+// LX2V_ATTN_QB=4|5 fixes NQB and LX2V_ATTN_TAIL=0 keeps everything in one launch (A/B switches,
+// read per call).
 int lx2v_attn_launch_x16(const lx2v_attn::AttnParams& p, hipStream_t st) {
   static int cus_cached[64];
   int dev = 0, cus = 256;
@@ -473,11 +478,29 @@ int lx2v_attn_launch_x16(const lx2v_attn::AttnParams& p, hipStream_t st) {
     }
     cus = cus_cached[dev];
   }
-  auto rounds = [&](int nqb_wave) { return ((int64_t)((p.sq + 64 * nqb_wave - 1) / (64 * nqb_wave)) * p.heads + cus - 1) / cus; };
+  auto blocks = [&](int nqb_wave) { return (int64_t)((p.sq + 64 * nqb_wave - 1) / (64 * nqb_wave)); };
+  auto rounds = [&](int nqb_wave) { return (blocks(nqb_wave) * p.heads + cus - 1) / cus; };
   int nqb_wave = (double)rounds(5) * 5 * 0.96 < (double)rounds(4) * 4 ? 5 : 4;
   if (const char* e = getenv("LX2V_ATTN_QB")) nqb_wave = atoi(e) == 5 ? 5 : 4;
   lx2v_attn::AttnParams pp = p;
-  pp.nqb = (p.sq + 64 * nqb_wave - 1) / (64 * nqb_wave);
-  if (nqb_wave == 5) return launch_with_rounds(attn_fwd_x16_kernel<true, 5>, attn_fwd_x16_kernel<false, 5>, X16_THREADS, pp, st, "attn_fwd(x16)");
-  return launch_with_rounds(attn_fwd_x16_kernel<true, 4>, attn_fwd_x16_kernel<false, 4>, X16_THREADS, pp, st, "attn_fwd(x16)");
+  pp.nqb = (int)blocks(nqb_wave);
+  int64_t nwg = (int64_t)pp.nqb * p.heads;
+  const int64_t rest = nwg % cus;
+  const char* tail_env = getenv("LX2V_ATTN_TAIL");
+  const bool split = nwg > cus && rest > 0 && rest <= pp.nqb && rest * 4 <= cus && !(tail_env != nullptr && atoi(tail_env) == 0);
+  if (split) nwg -= rest;
+  const int rc = nqb_wave == 5 ? launch_with_rounds(attn_fwd_x16_kernel<true, 5>, attn_fwd_x16_kernel<false, 5>, X16_THREADS, pp, nwg, st, "attn_fwd(x16)")
+                               : launch_with_rounds(attn_fwd_x16_kernel<true, 4>, attn_fwd_x16_kernel<false, 4>, X16_THREADS, pp, nwg, st, "attn_fwd(x16)");
+  if (rc != LX2V_OK || !split) return rc;
+  // the last `rest` query blocks of the last head
+  const int64_t row0 = (int64_t)(pp.nqb - rest) * 64 * nqb_wave;
+  lx2v_attn::AttnParams pt = p;
+  pt.q = p.q + row0 * p.ldq + (int64_t)(p.heads - 1) * HD;
+  pt.out = p.out + row0 * p.ldo + (int64_t)(p.heads - 1) * HD;
+  pt.k = p.k + (int64_t)(p.heads - 1) * HD;
+  pt.v = p.v + (int64_t)(p.heads - 1) * HD;
+  pt.heads = 1;
+  pt.sq = (int)(p.sq - row0);
+  pt.nqb = (pt.sq + 63) / 64;
+  return launch_with_rounds(attn_fwd_x16_kernel<true, 1>, attn_fwd_x16_kernel<false, 1>, X16_THREADS, pt, (int64_t)pt.nqb, st, "attn_fwd(x16 tail)");
 }

@@ -58,11 +58,11 @@ LX2V_DEVICE uint32_t cvt_pk_op(float lo, float hi) {
 
 __device__ __attribute__((aligned(64))) unsigned g_round_done[16];  // one copy per translation unit
 
-// Launch `kshort` (skv <= 2048) or `klong` over nqb * heads workgroups of `threads`, with round
-// alignment when a head's K/V outgrows an XCD's L2 (4 MiB) and there are many rounds.
+// Launch `kshort` (skv <= 2048) or `klong` over the first `nwg` of the nqb * heads workgroups
+// (head-major order) with `threads` threads each, with round alignment when a head's K/V outgrows
+// an XCD's L2 (4 MiB) and there are many rounds.
 template <class KS, class KL>
-int launch_with_rounds(KS kshort, KL klong, int threads, const lx2v_attn::AttnParams& p, hipStream_t st, const char* what) {
-  const int64_t nwg = (int64_t)p.nqb * p.heads;
+int launch_with_rounds(KS kshort, KL klong, int threads, const lx2v_attn::AttnParams& p, int64_t nwg, hipStream_t st, const char* what) {
   RoundSync rs{nullptr, 32};
   static const bool sync_off = [] { const char* e = getenv("LX2V_ATTN_ROUND_SYNC"); return e && atoi(e) == 0; }();
   if (!sync_off && (int64_t)p.skv * lx2v_attn::HD * 4 > (8 << 20)) {

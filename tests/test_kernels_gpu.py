@@ -200,6 +200,26 @@ def test_attention_matches_sdpa(cuda, attn_kernel, sq, skv, H):
     assert (out.float().cpu() - ref).abs().max().item() <= 2e-2 * max(ref.abs().max().item(), 1.0)
 
 
+@pytest.mark.parametrize("qb,H", [("4", 4), ("5", 5)])
+def test_attention_short_last_round_goes_to_a_second_launch(cuda, monkeypatch, qb, H):
+    """260 workgroups on a 256-CU part: the four left over after the last full round (the end of
+    the last head) are computed by a second launch with 64-row workgroups; every row must come
+    out the same as in the single-launch run and match the reference."""
+    monkeypatch.setenv("LX2V_ATTN_KERNEL", "x16")
+    monkeypatch.setenv("LX2V_ATTN_QB", qb)
+    sq, skv = 16640 - 37, 200
+    q, k, v = _rand((sq, H, 128), 40), _rand((skv, H, 128), 41), _rand((skv, H, 128), 42)
+    ref = R.sdpa(q.float(), k.float(), v.float())
+    qd, kd, vd = q.to(cuda), k.to(cuda), v.to(cuda)
+    out = hip.attn_fwd(qd, kd, vd)
+    monkeypatch.setenv("LX2V_ATTN_TAIL", "0")
+    one = hip.attn_fwd(qd, kd, vd)
+    assert torch.equal(out[: sq - 2048], one[: sq - 2048])
+    assert cos(out, ref) >= 0.9999 and cos(one, ref) >= 0.9999
+    assert (out.float().cpu() - ref).abs().max().item() <= 2e-2 * max(ref.abs().max().item(), 1.0)
+    assert (out.float() - one.float()).abs().max().item() <= 2e-2
+
+
 def test_attention_operand_layout_exact_integers(cuda, attn_kernel):
     """One-hot softmax (a single huge score per row) turns attention into a row gather of V with
     asymmetric integer data: any key/dim permutation mistake in the MFMA operand maps shows up."""
