@@ -486,7 +486,7 @@ def main():
                        "parallelism": f"cfg_p{cfg_p} x seq_p{seq_p} (ulysses)", "tokens": S, "dim": D, "heads": H, "ffn_dim": F, "layers": layers},
             "step_tflops": step_flops / 1e12,
             "achieved_tflops_per_gpu": step_flops / s_per_step / 1e12 / world,
-            "roofline": {"kernel": "attn_fwd_x16_kernel (self-attention)" if args.attn == "bf16" else "attn_fwd_fp8_kernel<false> + quantisation pre-pass (self-attention)",
+            "roofline": {"kernel": "attn_fwd_x16_kernel (self-attention: main launch + 64-row tail launch)" if args.attn == "bf16" else "attn_fwd_fp8_kernel<false> + quantisation pre-pass (self-attention)",
                          "bound": "mfma", "achieved": achieved, "peak": attn_peak(args),
                          "unit": "TFLOP/s", "frac": achieved / attn_peak(args),
                          "traffic": measured_traffic(S_pad, H // seq_p) if (args.attn == "bf16" and n_launches == layers * 2 * args.steps // cfg_p) else None,

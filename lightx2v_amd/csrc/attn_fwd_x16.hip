@@ -460,8 +460,8 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
 // Launch for p already validated by lx2v_attn_fwd_bf16 (no RoPE; K/V extent + 8 tiles < 4 GiB).
 // Query rows per workgroup = 4 waves x 16 NQB.  Five blocks per wave stream K/V a fifth less often
 // and measure about 4 % faster per row, but workgroups run in rounds of one per CU and a round
-// costs in proportion to NQB, so the choice goes by rounds x NQB (14B/720p: 47 x 4 against
-// 38 x 5 x 0.96; 1.3B/480p: 6 x 4 against 5 x 5 x 0.96).  When the last round would hold only a few
+// costs in proportion to NQB, so the choice goes by rounds x NQB (14B/720p: 46 x 4 + tail against
+// 37 x 5 x 0.96 + tail; 1.3B/480p: 6 x 4 against 5 x 5 x 0.96).  When the last round would hold only a few
 // workgroups, all of the last head, the main launch stops at the last full round and the
 // remaining query rows go to a second launch with one block per wave (64 rows per workgroup:
 // more, much shorter workgroups instead of a nearly empty full-length round; 14B/720p: 8 workgroups
@@ -478,17 +478,31 @@ int lx2v_attn_launch_x16(const lx2v_attn::AttnParams& p, hipStream_t st) {
     }
     cus = cus_cached[dev];
   }
-  auto blocks = [&](int nqb_wave) { return (int64_t)((p.sq + 64 * nqb_wave - 1) / (64 * nqb_wave)); };
-  auto rounds = [&](int nqb_wave) { return (blocks(nqb_wave) * p.heads + cus - 1) / cus; };
-  int nqb_wave = (double)rounds(5) * 5 * 0.96 < (double)rounds(4) * 4 ? 5 : 4;
+  auto blocks = [&](int m) { return (int64_t)((p.sq + 64 * m - 1) / (64 * m)); };
+  // the workgroups of a last round that is worth a second launch: few (one round of 64-row
+  // workgroups takes their rows) and all of the last head
+  auto tail_of = [&](int m) -> int64_t {
+    const int64_t wgs = blocks(m) * p.heads, rest = wgs % cus;
+    return (wgs > cus && rest > 0 && rest <= blocks(m) && rest * m <= cus) ? rest : 0;
+  };
+  const char* tail_env = getenv("LX2V_ATTN_TAIL");
+  const bool tail_on = !(tail_env != nullptr && atoi(tail_env) == 0);
+  // cost in units of "one round of 64 rows per wave": a round of m blocks costs m (0.96 m for
+  // m = 5), a tail launch about 1.3
+  auto cost = [&](int m) {
+    const int64_t wgs = blocks(m) * p.heads;
+    const double per_round = m == 5 ? 0.96 * m : (double)m;
+    if (tail_on && tail_of(m) > 0) return (double)(wgs / cus) * per_round + 1.3;
+    return (double)((wgs + cus - 1) / cus) * per_round;
+  };
+  int nqb_wave = cost(5) < cost(4) ? 5 : 4;
   if (const char* e = getenv("LX2V_ATTN_QB")) nqb_wave = atoi(e) == 5 ? 5 : 4;
   lx2v_attn::AttnParams pp = p;
   pp.nqb = (int)blocks(nqb_wave);
   int64_t nwg = (int64_t)pp.nqb * p.heads;
-  const int64_t rest = nwg % cus;
-  const char* tail_env = getenv("LX2V_ATTN_TAIL");
-  const bool split = nwg > cus && rest > 0 && rest <= pp.nqb && rest * 4 <= cus && !(tail_env != nullptr && atoi(tail_env) == 0);
-  if (split) nwg -= rest;
+  const int64_t rest = tail_on ? tail_of(nqb_wave) : 0;
+  const bool split = rest > 0;
+  nwg -= rest;
   const int rc = nqb_wave == 5 ? launch_with_rounds(attn_fwd_x16_kernel<true, 5>, attn_fwd_x16_kernel<false, 5>, X16_THREADS, pp, nwg, st, "attn_fwd(x16)")
                                : launch_with_rounds(attn_fwd_x16_kernel<true, 4>, attn_fwd_x16_kernel<false, 4>, X16_THREADS, pp, nwg, st, "attn_fwd(x16)");
   if (rc != LX2V_OK || !split) return rc;
