@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: SQ counters of the self-attention launch for kernel $1 (w4 | x16), printed per launch.
+# GPU box: SQ counters of the self-attention launch for kernel $1 (w4 | x16), printed per self-attention call.
 set -o pipefail
 cd "$(dirname "$0")/.."
 export LX2V_ATTN_KERNEL=$1
@@ -9,10 +9,10 @@ timeout -s KILL 90 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAI
 f=$(find $d -name "*counter_collection.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys, collections
-acc = collections.defaultdict(list)
+acc = collections.defaultdict(lambda: collections.defaultdict(list))   # counter -> kernel symbol -> values
 for r in csv.DictReader(open(sys.argv[1])):
     if "attn_fwd" in r["Kernel_Name"]:
-        acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-for k, v in sorted(acc.items()):
-    print(f"{k:28s} {sum(v)/len(v):.4g}")
+        acc[r["Counter_Name"]][r["Kernel_Name"]].append(float(r["Counter_Value"]))
+for k, by in sorted(acc.items()):   # per self-attention call: the means of its launches (main + tail) summed
+    print(f"{k:28s} {sum(sum(v) / len(v) for v in by.values()):.4g}")
 PY
