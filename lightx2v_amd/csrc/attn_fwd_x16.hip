@@ -6,7 +6,7 @@
 // moves half the accumulator traffic of 32x32x16 per cycle, and under the chip's power limit the
 // same softmax filler stream beside it sustains about 13 % more FLOP/s.
 //
-// Per wave: NQB = 4 or 5 blocks of 16 query rows (qb).  A half tile of 32 keys is two key blocks (kb).
+// Per wave: NQB = 4 or 5 (1 in the tail launch) blocks of 16 query rows (qb).  A half tile of 32 keys is two key blocks (kb).
 //   QK(k): S[kb][qb] = K(kb) Q(qb)^T - m   2 kb x 4 k-steps of 32 channels x NQB = 8 NQB MFMAs
 //   SM(k): exp2 / row sum / bf16 convert of the 8 NQB scores a lane holds
 //   PV(k): O[qb][db] += V(db)^T P(qb)      8 blocks of 16 channels (db) x NQB = 8 NQB MFMAs, the
