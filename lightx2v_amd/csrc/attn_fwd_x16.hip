@@ -15,7 +15,7 @@
 // ones) and the NQB MFMAs (one per qb) that use it; a period has 16 steps = 16 NQB MFMAs.  An
 // MFMA of this shape holds vector issue for 8 of its 16 cycles, so each gap takes 8 cycles of
 // other work; the softmax of 4 NQB score pairs fills the 16 NQB gaps exactly, four gaps a pair:
-// exp | add + convert | exp | add.  With NQB = 5 (448 registers) a workgroup covers 320 query
+// exp | exp | add + convert | add.  With NQB = 5 (448 registers) a workgroup covers 320 query
 // rows, so K/V are streamed from L2 a fifth less often and every fragment read, DMA piece and
 // wait is shared by five MFMAs instead of four.
 //
@@ -286,9 +286,11 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
       const u32x4 f = ring[s & 3];
       // One gap per query block: the MFMA, then what is not VALU work (it issues in the MFMA's
       // shadow), then the gap's share of the softmax.  Gap G = NQB s + qb of the period carries
-      // phase G & 3 of pair G >> 2:  0 first exp | 1 row-sum add and conversion of the previous
-      // pair | 2 second exp | 3 second add of the previous pair.  Consumers run a pair behind their
-      // exps, so that no instruction waits on a transcendental just issued.
+      // phase G & 3 of pair G >> 2:  0 first exp | 1 second exp | 2 row-sum add and conversion of
+      // the previous pair | 3 second add of the previous pair (this order measured 66.5 cycles per
+      // four gaps in isolation, exp | add + convert | exp | add 70.3: tools/probe_valu_beside_mfma.hip).
+      // Consumers run a pair behind their exps, so that no instruction waits on a transcendental
+      // just issued.
       static_for<0, NQB>([&](auto qbc) __attribute__((always_inline)) {
         constexpr int qb = decltype(qbc)::value, G = NQB * s + qb, pr = G >> 2, ph = G & 3;
         constexpr int sq = pr >> 2, sj = pr & 3, pq = (pr - 1) >> 2, pj = (pr - 1) & 3;
@@ -336,12 +338,12 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
           if constexpr (ph == 0) {
             if constexpr (X16_ABL & 128) ea[pr] = Sc[sj >> 1][sq][2 * (sj & 1)];
             else ea[pr] = exp2_op(Sc[sj >> 1][sq][2 * (sj & 1)]);
-          } else if constexpr (ph == 2) {
+          } else if constexpr (ph == 1) {
             if constexpr (X16_ABL & 128) eb[pr] = Sc[sj >> 1][sq][2 * (sj & 1) + 1];
             else eb[pr] = exp2_op(Sc[sj >> 1][sq][2 * (sj & 1) + 1]);
             if constexpr (X16_ABL & 256) asm volatile("" :: "v"(ea[pr]), "v"(eb[pr]));
           } else if constexpr (pr > 0 && !(X16_ABL & 256)) {
-            if constexpr (ph == 1) {
+            if constexpr (ph == 2) {
               add_op(ls[pq], ea[pr - 1]);
               Pc[pq][pj] = cvt_pk_op(ea[pr - 1], eb[pr - 1]);
             } else {
