@@ -278,7 +278,7 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
     // 0, 4, 8, 10 of the even periods (before their barrier, so that the count there is the same
     // on every trip), 4, 8, 12, 14 of the odd ones (well after the barrier that released the slot).
     const uint32_t dma_soff = __builtin_amdgcn_readfirstlane(PAR == 1 ? (uint32_t)(t + 4) * k_tile_bytes : (uint32_t)(t + 2) * v_tile_bytes);
-    bf16x4 vlo;
+    bf16x4 vlo, vhi;
     static_for<0, 16>([&](auto sc) __attribute__((always_inline)) {
       constexpr int s = decltype(sc)::value, m = s >> 1;
       constexpr int dma_i = PAR == 1 ? (s == 4 ? 0 : s == 8 ? 1 : s == 12 ? 2 : s == 14 ? 3 : -1) : (s == 0 ? 0 : s == 4 ? 1 : s == 8 ? 2 : s == 10 ? 3 : -1);
@@ -300,11 +300,22 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
         } else {
           mfma_pv(o[qb][m], f, Pp[qb]);
         }
+        // Where the step's non-VALU instructions go: beside this MFMA shape an LDS read is free
+        // in a gap with spare issue time and costs 3 cycles in an "add" gap (phase 3), 7 in an
+        // "add + convert" or second "exp" gap, 10 in a first "exp" gap (tools/probe_valu_beside_mfma.hip).
+        // So the claim of the next fragment and the read that replaces this step's go to the step's
+        // phase-3 gap (G3), the other read / the DMA to a phase-1 or -2 gap behind gap 0 (GX), the
+        // M0 update of the DMA stays in gap 0.
+        constexpr int p0 = (NQB * s) & 3;                      // phase of the step's gap 0
+        constexpr int G3 = NQB == 1 ? 0 : (3 - p0 + 4) & 3;     // first gap with phase 3 (NQB >= 4: always < NQB)
+        constexpr int GX = NQB == 1 ? 0 : (((1 - p0 + 4) & 3) != 0 ? ((1 - p0 + 4) & 3) : ((2 - p0 + 4) & 3));  // phase 1, or phase 2 when phase 1 is gap 0
+        static_assert(NQB == 1 || (G3 < NQB && GX < NQB && GX != G3 && GX != 0), "gap placement");
         if constexpr (qb == 0 && DMA) {
           if constexpr (PAR == 1) dma_m0(IntC<K_RING + BUF * KV_TILE_BYTES + 4096 * dma_i>{});
           else dma_m0(IntC<V_RING + ((BUF + 2) % RING) * KV_TILE_BYTES + 4096 * dma_i>{});
+          if constexpr (NQB == 1) asm volatile("s_nop 0");  // M0 write -> use, same gap
         }
-        if constexpr (qb == (NQB > 1 ? 1 : 0)) {
+        if constexpr (qb == GX) {
           if constexpr ((s & 1) == 1 && !(X16_ABL & (2 | 64))) {  // first of the two V^T reads of the fragment four steps on
             if constexpr (s + 4 < 16) vlo = frag_read_v(parc, bufc, IntC<s + 4>{}, IntC<0>{});
             else if constexpr (PAR == 0) vlo = frag_read_v(IntC<1>{}, bufc, IntC<s - 12>{}, IntC<0>{});
@@ -315,10 +326,10 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
             else dma_go(v_rs, v_vo[dma_i], dma_soff);
           }
         }
-        if constexpr (qb == NQB - 1) {
+        if constexpr (qb == G3) {
           // The next step's fragment is claimed here, so that the compiler's wait for it is issued
-          // in this MFMA's shadow instead of in front of the next one; then the fragment of step
-          // s + 4 replaces this step's.
+          // in an MFMA's shadow instead of in front of the next step; then the fragment of step
+          // s + 4 is requested (it lands in fresh registers: this step's later MFMAs keep f).
           asm volatile("" :: "v"(ring[(s + 1) & 3]));
           if constexpr ((X16_ABL & 2) || ((X16_ABL & 32) && (s & 1) == 0) || ((X16_ABL & 64) && (s & 1) == 1)) {
             asm volatile("" : "+v"(ring[s & 3]));
@@ -327,13 +338,13 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
             else if constexpr (PAR == 0) ring[s & 3] = frag_read_k(IntC<1>{}, bufc, IntC<s - 12>{});
             else ring[s & 3] = frag_read_k(IntC<0>{}, IntC<(BUF + 1) % RING>{}, IntC<s - 12>{});
           } else {
-            bf16x4 vhi;
             if constexpr (s + 4 < 16) vhi = frag_read_v(parc, bufc, IntC<s + 4>{}, IntC<1>{});
             else if constexpr (PAR == 0) vhi = frag_read_v(IntC<1>{}, bufc, IntC<s - 12>{}, IntC<1>{});
             else vhi = frag_read_v(IntC<0>{}, IntC<(BUF + 1) % RING>{}, IntC<s - 12>{}, IntC<1>{});
-            ring[s & 3] = __builtin_bit_cast(u32x4, __builtin_shufflevector(vlo, vhi, 0, 1, 2, 3, 4, 5, 6, 7));
           }
         }
+        if constexpr (qb == NQB - 1 && (s & 1) == 1 && !((X16_ABL & 2) || (X16_ABL & 64)))
+          ring[s & 3] = __builtin_bit_cast(u32x4, __builtin_shufflevector(vlo, vhi, 0, 1, 2, 3, 4, 5, 6, 7));
         if constexpr (!(X16_ABL & 1)) {
           if constexpr (ph == 0) {
             if constexpr (X16_ABL & 128) ea[pr] = Sc[sj >> 1][sq][2 * (sj & 1)];

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k(const u32x4* in, float* out, int iters,
   for (int i = 0; i < 8; ++i) r += e[i];
   out[blockIdx.x * 256 + threadIdx.x] = r;
 }
-// gap pattern: eight masks (1 exp, 2 add, 4 convert, 8 = exp issued last, 16 = a second add), repeated over the 64 gaps
+// gap pattern: eight masks (1 exp, 2 add, 4 convert, 8 = exp issued last, 16 = a second add, 32 = a ds_read_b128 directly behind the MFMA), repeated over the 64 gaps
 template <int M0, int M1, int M2, int M3, int M4 = M0, int M5 = M1, int M6 = M2, int M7 = M3>
 __global__ __launch_bounds__(256) void kp(const u32x4* in, float* out, int iters, long long* cyc) {
   const int lane = threadIdx.x & 63;
@@ -52,6 +52,11 @@ __global__ __launch_bounds__(256) void kp(const u32x4* in, float* out, int iters
   unsigned pk[8] = {};
   for (int i = 0; i < 8; ++i) { x[i] = -0.01f * (lane + i); e[i] = 0.f; }
   f32x4 c16[8] = {};
+  __shared__ u32x4 lds[1024];
+  for (int i = threadIdx.x; i < 1024; i += 256) lds[i] = in[i];
+  __syncthreads();
+  const unsigned laddr = (unsigned)(size_t)(__attribute__((address_space(3))) u32x4*)(lds + lane);
+  u32x4 sink[4] = {};
   const long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
     sfor<0, 64>([&](auto jc) __attribute__((always_inline)) {
@@ -59,6 +64,7 @@ __global__ __launch_bounds__(256) void kp(const u32x4* in, float* out, int iters
       constexpr int MS[8] = {M0, M1, M2, M3, M4, M5, M6, M7};
       constexpr int M = MS[j & 7];
       asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c16[j & 7]) : "v"(a[j & 7]), "v"(b[(j >> 3) & 7]));
+      if constexpr (M & 32) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(sink[j & 3]) : "v"(laddr), "i"(1024 * (j & 7)));
       if constexpr ((M & 1) && !(M & 8)) asm volatile("v_exp_f32 %0, %1" : "=v"(e[j & 7]) : "v"(x[j & 7]));
       if constexpr (M & 2) asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc[j & 3]) : "v"(e[(j + 4) & 7]));
       if constexpr (M & 16) asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc[(j + 1) & 3]) : "v"(e[(j + 6) & 7]));
@@ -69,7 +75,8 @@ __global__ __launch_bounds__(256) void kp(const u32x4* in, float* out, int iters
   }
   const long long t1 = __builtin_readcyclecounter();
   if (blockIdx.x == 0 && threadIdx.x == 0) cyc[0] = t1 - t0;
-  float r = acc[0] + acc[1] + acc[2] + acc[3];
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sink[0]), "+v"(sink[1]), "+v"(sink[2]), "+v"(sink[3]));
+  float r = acc[0] + acc[1] + acc[2] + acc[3] + (float)(sink[0][0] + sink[1][1] + sink[2][2] + sink[3][3]);
   for (int j = 0; j < 8; ++j) for (int q = 0; q < 4; ++q) r += c16[j][q];
   for (int i = 0; i < 8; ++i) r += e[i] + (float)pk[i];
   out[blockIdx.x * 256 + threadIdx.x] = r;
@@ -116,5 +123,13 @@ int main() {
   runp(kp<0, 0, 6, 2>, "- | - | AC | A (consumers only)");
   runp(kp<0, 0, 2, 2>, "- | - | A | A");
   runp(kp<0, 0, 4, 0>, "- | - | C | -");
+  runp(kp<33, 1, 6, 2>, "RE | E | AC | A");
+  runp(kp<1, 33, 6, 2>, "E | RE | AC | A");
+  runp(kp<1, 1, 38, 2>, "E | E | RAC | A");
+  runp(kp<1, 1, 6, 34>, "E | E | AC | RA");
+  runp(kp<33, 1, 6, 34>, "RE | E | AC | RA");
+  runp(kp<1, 1, 6, 34, 1, 1, 6, 2>, "E | E | AC | RA | E | E | AC | A");
+  runp(kp<32, 0, 0, 0>, "R | - | - | -");
+  runp(kp<32, 32, 32, 32>, "R | R | R | R");
   return 0;
 }
