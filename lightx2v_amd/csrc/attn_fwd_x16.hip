@@ -303,9 +303,9 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
         // Where the step's non-VALU instructions go: beside this MFMA shape an LDS read is free
         // in a gap with spare issue time and costs 3 cycles in an "add" gap (phase 3), 7 in an
         // "add + convert" or second "exp" gap, 10 in a first "exp" gap (tools/probe_valu_beside_mfma.hip).
-        // So the claim of the next fragment and the read that replaces this step's go to the step's
-        // phase-3 gap (G3), the other read / the DMA to a phase-1 or -2 gap behind gap 0 (GX), the
-        // M0 update of the DMA stays in gap 0.
+        // So the read that replaces this step's fragment goes to the step's phase-3 gap (G3), the
+        // other read / the DMA to a phase-1 or -2 gap behind gap 0 (GX), the M0 update of the DMA
+        // stays in gap 0.
         constexpr int p0 = (NQB * s) & 3;                      // phase of the step's gap 0
         constexpr int G3 = NQB == 1 ? 0 : (3 - p0 + 4) & 3;     // first gap with phase 3 (NQB >= 4: always < NQB)
         constexpr int GX = NQB == 1 ? 0 : (((1 - p0 + 4) & 3) != 0 ? ((1 - p0 + 4) & 3) : ((2 - p0 + 4) & 3));  // phase 1, or phase 2 when phase 1 is gap 0
@@ -315,6 +315,11 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
           else dma_m0(IntC<V_RING + ((BUF + 2) % RING) * KV_TILE_BYTES + 4096 * dma_i>{});
           if constexpr (NQB == 1) asm volatile("s_nop 0");  // M0 write -> use, same gap
         }
+        // The next step's fragment is claimed in the step's last phase-2 gap, so that the compiler's
+        // wait for it is issued in an MFMA's shadow instead of in front of the next step (a wait
+        // costs nothing extra there; next to the read in the phase-3 gap it would cost 4 cycles).
+        constexpr int GW = ((2 - p0 + 4) & 3) + (((2 - p0 + 4) & 3) + 4 < NQB ? 4 : 0);
+        if constexpr (NQB > 1 && qb == GW) asm volatile("" :: "v"(ring[(s + 1) & 3]));
         if constexpr (qb == GX) {
           if constexpr ((s & 1) == 1 && !(X16_ABL & (2 | 64))) {  // first of the two V^T reads of the fragment four steps on
             if constexpr (s + 4 < 16) vlo = frag_read_v(parc, bufc, IntC<s + 4>{}, IntC<0>{});
@@ -327,10 +332,9 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
           }
         }
         if constexpr (qb == G3) {
-          // The next step's fragment is claimed here, so that the compiler's wait for it is issued
-          // in an MFMA's shadow instead of in front of the next step; then the fragment of step
-          // s + 4 is requested (it lands in fresh registers: this step's later MFMAs keep f).
-          asm volatile("" :: "v"(ring[(s + 1) & 3]));
+          // The fragment of step s + 4 is requested (it lands in fresh registers: this step's later
+          // MFMAs keep f).
+          if constexpr (NQB == 1) asm volatile("" :: "v"(ring[(s + 1) & 3]));
           if constexpr ((X16_ABL & 2) || ((X16_ABL & 32) && (s & 1) == 0) || ((X16_ABL & 64) && (s & 1) == 1)) {
             asm volatile("" : "+v"(ring[s & 3]));
           } else if constexpr ((s & 1) == 0) {

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k(const u32x4* in, float* out, int iters,
   for (int i = 0; i < 8; ++i) r += e[i];
   out[blockIdx.x * 256 + threadIdx.x] = r;
 }
-// gap pattern: eight masks (1 exp, 2 add, 4 convert, 8 = exp issued last, 16 = a second add, 32 = a ds_read_b128 directly behind the MFMA), repeated over the 64 gaps
+// gap pattern: eight masks (1 exp, 2 add, 4 convert, 8 = exp issued last, 16 = a second add, 32 = a ds_read_b128 directly behind the MFMA, 64 = a second one, 128 = s_waitcnt lgkmcnt(8), 256 = s_add_u32 m0), repeated over the 64 gaps
 template <int M0, int M1, int M2, int M3, int M4 = M0, int M5 = M1, int M6 = M2, int M7 = M3>
 __global__ __launch_bounds__(256) void kp(const u32x4* in, float* out, int iters, long long* cyc) {
   const int lane = threadIdx.x & 63;
@@ -65,6 +65,9 @@ __global__ __launch_bounds__(256) void kp(const u32x4* in, float* out, int iters
       constexpr int M = MS[j & 7];
       asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c16[j & 7]) : "v"(a[j & 7]), "v"(b[(j >> 3) & 7]));
       if constexpr (M & 32) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(sink[j & 3]) : "v"(laddr), "i"(1024 * (j & 7)));
+      if constexpr (M & 128) asm volatile("s_waitcnt lgkmcnt(8)");
+      if constexpr (M & 64) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(sink[(j + 1) & 3]) : "v"(laddr), "i"(1024 * ((j + 3) & 7)));
+      if constexpr (M & 256) asm volatile("s_add_u32 m0, %0, 0x1000" :: "s"(iters) : "scc");
       if constexpr ((M & 1) && !(M & 8)) asm volatile("v_exp_f32 %0, %1" : "=v"(e[j & 7]) : "v"(x[j & 7]));
       if constexpr (M & 2) asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc[j & 3]) : "v"(e[(j + 4) & 7]));
       if constexpr (M & 16) asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc[(j + 1) & 3]) : "v"(e[(j + 6) & 7]));
@@ -129,6 +132,14 @@ int main() {
   runp(kp<1, 1, 6, 34>, "E | E | AC | RA");
   runp(kp<33, 1, 6, 34>, "RE | E | AC | RA");
   runp(kp<1, 1, 6, 34, 1, 1, 6, 2>, "E | E | AC | RA | E | E | AC | A");
+  runp(kp<1, 1, 6, 98>, "E | E | AC | RRA");
+  runp(kp<1, 1, 6, 162>, "E | E | AC | WRA");
+  runp(kp<1, 1, 6, 226>, "E | E | AC | WRRA");
+  runp(kp<1, 1, 6, 130>, "E | E | AC | WA");
+  runp(kp<129, 1, 6, 2>, "WE | E | AC | A");
+  runp(kp<257, 1, 6, 2>, "ME | E | AC | A");
+  runp(kp<1, 1, 6, 258>, "E | E | AC | MA");
+  runp(kp<1, 1, 6, 34, 1, 1, 6, 34>, "E | E | AC | RA (x2)");
   runp(kp<32, 0, 0, 0>, "R | - | - | -");
   runp(kp<32, 32, 32, 32>, "R | R | R | R");
   return 0;
