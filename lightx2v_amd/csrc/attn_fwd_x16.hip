@@ -347,7 +347,7 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
             else vhi = frag_read_v(IntC<0>{}, IntC<(BUF + 1) % RING>{}, IntC<s - 12>{}, IntC<1>{});
           }
         }
-        if constexpr (qb == NQB - 1 && (s & 1) == 1 && !((X16_ABL & 2) || (X16_ABL & 64)))
+        if constexpr (qb == NQB - 1 && (s & 1) == 1 && !(X16_ABL & (2 | 64)))
           ring[s & 3] = __builtin_bit_cast(u32x4, __builtin_shufflevector(vlo, vhi, 0, 1, 2, 3, 4, 5, 6, 7));
         if constexpr (!(X16_ABL & 1)) {
           if constexpr (ph == 0) {
