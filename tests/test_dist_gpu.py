@@ -21,6 +21,26 @@ def _free_port():
     return port
 
 
+def _spawn(fn, args, nprocs, attempt_s=120, attempts=2):
+    """mp.spawn with a deadline per attempt.  gloo moving CUDA tensors of processes that share one
+    GPU stalls once in a while (a transport artefact of this one-GPU stand-in, not of the code under
+    test); a stalled attempt is ended by killing exactly the processes it started, and run again
+    on a fresh port.  `args` is called with the port to build the worker arguments."""
+    import time
+    for k in range(attempts):
+        ctx = mp.spawn(fn, args=args(_free_port()), nprocs=nprocs, join=False)
+        t_end = time.time() + attempt_s
+        while time.time() < t_end:
+            if ctx.join(timeout=1.0):   # raises if a worker failed
+                return
+        for pr in ctx.processes:
+            if pr.is_alive():
+                pr.kill()
+        for pr in ctx.processes:
+            pr.join(10)
+    pytest.fail(f"{fn.__name__}: {attempts} attempts of {attempt_s} s each stalled")
+
+
 def _worker(rank, world, port, out_dir, fused, fp8_comm=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -64,7 +84,7 @@ def test_sequence_parallel_block_two_ranks_one_gpu(cuda, tmp_path, fused):
     from tests.util import case_inputs, cos, load_golden
 
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), fused), nprocs=world, join=True)
+    _spawn(_worker, lambda port: (world, port, str(tmp_path), fused), world)
     rec = load_golden("small_d512_g3x5x7")
     c = case_inputs(rec)
     got = torch.cat([torch.load(os.path.join(str(tmp_path), f"o{r}_{int(fused)}.pt")) for r in range(world)])[:c["S"]]
@@ -89,8 +109,8 @@ def test_sequence_parallel_block_fp8_payload(cuda, tmp_path, fused):
     from tests.util import case_inputs, cos, load_golden
 
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), fused, True), nprocs=world, join=True)
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), fused, False), nprocs=world, join=True)
+    _spawn(_worker, lambda port: (world, port, str(tmp_path), fused, True), world)
+    _spawn(_worker, lambda port: (world, port, str(tmp_path), fused, False), world)
     c = case_inputs(load_golden("small_d512_g3x5x7"))
     got8 = torch.cat([torch.load(os.path.join(str(tmp_path), f"o{r}_{int(fused)}_fp8.pt")) for r in range(world)])[:c["S"]]
     got = torch.cat([torch.load(os.path.join(str(tmp_path), f"o{r}_{int(fused)}.pt")) for r in range(world)])[:c["S"]]
@@ -143,7 +163,7 @@ def test_hunyuan_double_blocks_sequence_parallel_two_ranks_one_gpu(cuda, tmp_pat
     from tests.util import cos, load_golden
 
     world = 2
-    mp.spawn(_hy_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    _spawn(_hy_worker, lambda port: (world, port, str(tmp_path)), world)
     res = [torch.load(os.path.join(str(tmp_path), f"hy{r}.pt")) for r in range(world)]
     rec = load_golden("hy_tiny_d256")
     got = torch.cat([r["final"][0] for r in res])
