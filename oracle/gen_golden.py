@@ -114,7 +114,7 @@ def _sha(t: torch.Tensor) -> str:
     return hashlib.sha256(t.contiguous().numpy().tobytes()).hexdigest()
 
 
-def run_case(name, grid, dim, heads, ffn, text_len, seed, out_dir, full, stride_rows=None):
+def run_case(name, grid, dim, heads, ffn, text_len, seed, out_dir, full, stride_rows=None, stages_keep=None):
     from lightx2v.models.networks.wan.infer.module_io import GridOutput, WanPreInferModuleOutput
 
     f, h, w_ = grid
@@ -203,7 +203,7 @@ def run_case(name, grid, dim, heads, ffn, text_len, seed, out_dir, full, stride_
         rec["x_out"] = x_ref[rows].numpy()
         rec["head_out"] = head_ref[rows].numpy()
         for k, v in trace.stages.items():
-            if v.shape[0] == S:
+            if v.shape[0] == S and (stages_keep is None or k in stages_keep):
                 rec["stage_" + k] = v[rows].numpy()
     os.makedirs(out_dir, exist_ok=True)
     np.savez_compressed(os.path.join(out_dir, f"{name}.npz"), **rec)
@@ -267,9 +267,14 @@ def main():
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
     ap.add_argument("--big", action="store_true", help="also run the full 32760-token config-1 block (20+ s, 201 MB tensors)")
+    ap.add_argument("--dims14b", action="store_true", help="only the block at Wan2.1-14B dims (D=5120, H=40, F=13824; 1.4 GB of fp32 weights)")
     args = ap.parse_args()
     _install_reference(args.ref)
     torch.manual_seed(0)
+    if args.dims14b:
+        keep = {"self_attn_out", "self_attn_y", "x_after_self", "cross_attn_y", "x_after_cross", "ffn_y", "x_out"}
+        run_case("wan14b_g3x30x52", (3, 30, 52), 5120, 40, 13824, 512, seed=6, out_dir=args.out, full=False, stride_rows=199, stages_keep=keep)
+        return
     # tiny full-tensor goldens (reduced D) and 1.3B-dim strided goldens
     run_case("tiny_d256_g2x4x4", (2, 4, 4), 256, 2, 512, 16, seed=1, out_dir=args.out, full=True)
     run_case("tiny_d256_g3x6x8", (3, 6, 8), 256, 2, 512, 40, seed=2, out_dir=args.out, full=True)

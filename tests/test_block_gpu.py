@@ -10,7 +10,7 @@ import torch
 
 import lightx2v_amd as L
 from oracle import wan_block_ref as R
-from tests.util import BLOCK_CASES, case_inputs, cos, golden_rows, load_golden
+from tests.util import BLOCK_CASES, cached_case, case_inputs, cos, golden_rows, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -48,8 +48,7 @@ def _bf16_residual_floor(rec, c, rows):
 @pytest.mark.parametrize("name", BLOCK_CASES)
 @pytest.mark.parametrize("mode", ["fused", "op_by_op", "rope_in_attn"])
 def test_block_vs_reference_golden(cuda, name, mode):
-    rec = load_golden(name)
-    c = case_inputs(rec)
+    rec, c = cached_case(name)
     kw = {"fused": {}, "op_by_op": {"fused_block": False}, "rope_in_attn": {"rope_type": "hip_attn"}}[mode]
     W, inf = _build(c, cuda, **kw)
     pre = _pre(c, cuda)
