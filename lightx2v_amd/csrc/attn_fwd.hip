@@ -392,19 +392,15 @@ extern "C" int lx2v_attn_fwd_bf16(const uint16_t* q, int64_t ldq, const uint16_t
   // for the 8-wave one.  Of the two, the 16x16x32 kernel is the default (it needs more cycles than
   // the 32x32x16 one but the chip holds a higher clock under it); LX2V_ATTN_KERNEL=w4 selects the
   // 32x32x16 kernel.
-  const char* which = getenv("LX2V_ATTN_KERNEL");  // A/B switch, read per call
-  const int kernel = which == nullptr ? 16 : strcmp(which, "w8") == 0 ? 8 : strcmp(which, "w4") == 0 ? 4 : 16;
+  const int kernel = lx2v_options().attn_kernel;
   if (rope_cos_sin == nullptr && kernel != 8) {
     const int rc = kernel == 16 ? lx2v_attn_launch_x16(p, st) : lx2v_attn_launch_w4(p, st);
     if (rc != LX2V_OK) return rc;
     LX2V_CHECK_LAUNCH("attn_fwd(one wave per SIMD)");
     return LX2V_OK;
   }
-  // Tuning switch LX2V_ATTN_VARIANT (8-wave kernel): 0 = plain order, 1 (default) = pipelined K-fragment reads.
-  static const int variant = [] {
-    const char* e = getenv("LX2V_ATTN_VARIANT");
-    return (e && atoi(e) == 0) ? 0 : 1;
-  }();
+  // Tuning switch attn_variant (8-wave kernel): 0 = plain order, 1 (default) = pipelined K-fragment reads.
+  const int variant = lx2v_options().attn_variant;
 #define LX2V_ATTN_LAUNCH(R, SK)                                                                  \
   do {                                                                                           \
     if (variant == 0) hipLaunchKernelGGL((attn_fwd_kernel<R, SK, 0>), grid, block, 0, st, p);       \

@@ -488,8 +488,7 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
 // remaining query rows go to a second launch with one block per wave (64 rows per workgroup:
 // more, much shorter workgroups instead of a nearly empty full-length round; 14B/720p: 8 workgroups
 // of 320 rows become 37 of 64, 77.4 -> 76.1 ms per launch).
-// LX2V_ATTN_QB=4|5 fixes NQB and LX2V_ATTN_TAIL=0 keeps everything in one launch (A/B switches,
-// read per call).
+// Options attn_qb = 4|5 fix NQB and attn_tail = 0 keeps everything in one launch (A/B switches).
 int lx2v_attn_launch_x16(const lx2v_attn::AttnParams& p, hipStream_t st) {
   static int cus_cached[64];
   int dev = 0, cus = 256;
@@ -507,8 +506,7 @@ int lx2v_attn_launch_x16(const lx2v_attn::AttnParams& p, hipStream_t st) {
     const int64_t wgs = blocks(m) * p.heads, rest = wgs % cus;
     return (wgs > cus && rest > 0 && rest <= blocks(m) && rest * m <= cus) ? rest : 0;
   };
-  const char* tail_env = getenv("LX2V_ATTN_TAIL");
-  const bool tail_on = !(tail_env != nullptr && atoi(tail_env) == 0);
+  const bool tail_on = lx2v_options().attn_tail != 0;
   // cost in units of "one round of 64 rows per wave": a round of m blocks costs m (0.96 m for
   // m = 5), a tail launch about 1.3
   auto cost = [&](int m) {
@@ -518,7 +516,7 @@ int lx2v_attn_launch_x16(const lx2v_attn::AttnParams& p, hipStream_t st) {
     return (double)((wgs + cus - 1) / cus) * per_round;
   };
   int nqb_wave = cost(5) < cost(4) ? 5 : 4;
-  if (const char* e = getenv("LX2V_ATTN_QB")) nqb_wave = atoi(e) == 5 ? 5 : 4;
+  if (lx2v_options().attn_qb != 0) nqb_wave = lx2v_options().attn_qb;
   lx2v_attn::AttnParams pp = p;
   pp.nqb = (int)blocks(nqb_wave);
   int64_t nwg = (int64_t)pp.nqb * p.heads;

@@ -5,6 +5,8 @@
 
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "attn_common.h"
 
 namespace {
@@ -16,11 +18,18 @@ namespace {
 // rounds (deep prefetch hides the misses that would hold a leader back) and every CU ends up
 // streaming K/V from memory on its own.  So a workgroup of round r waits, with a time limit, until
 // the XCD's previous round has finished.  Only a locality hint: any counter value is safe.
+//
+// The counters only ever grow.  A launch gets one of kRoundSlots counter sets and the values they
+// will hold when it starts (`base`, tracked on the host: a launch of n workgroups adds exactly
+// n/8 (+1) to each XCD's counter), so nothing is reset between launches and launches that overlap
+// on different streams do not share counters.
 struct RoundSync {
-  unsigned* done;   // [8] finished workgroups per XCD, zeroed before the launch; null = off
+  unsigned* done;    // [8] finished workgroups per XCD of this launch's slot; null = off
+  unsigned base[8];  // their values before this launch's first workgroup
   int cus_per_xcd;
 };
 constexpr long long kRoundWaitTicks = 10000;  // 100 us of the 100 MHz wall clock
+constexpr int kRoundSlots = 64;
 
 // Entry of a workgroup: wait (bounded) for the XCD's previous round.  Ends in a workgroup barrier
 // when alignment is on.
@@ -28,9 +37,9 @@ LX2V_DEVICE void round_enter(const RoundSync& rs) {
   if (rs.done != nullptr) {
     const unsigned round = (blockIdx.x >> 3) / rs.cus_per_xcd;
     if (round > 0 && threadIdx.x == 0) {
-      const unsigned want = round * rs.cus_per_xcd;
+      const unsigned want = rs.base[blockIdx.x & 7] + round * rs.cus_per_xcd;
       const long long t_end = wall_clock64() + kRoundWaitTicks;
-      while (__hip_atomic_load(rs.done + (blockIdx.x & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && wall_clock64() < t_end)
+      while ((int)(__hip_atomic_load(rs.done + (blockIdx.x & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0 && wall_clock64() < t_end)
         __builtin_amdgcn_s_sleep(16);
     }
     __syncthreads();
@@ -56,37 +65,66 @@ LX2V_DEVICE uint32_t cvt_pk_op(float lo, float hi) {
   return r;
 }
 
-__device__ __attribute__((aligned(64))) unsigned g_round_done[16];  // one copy per translation unit
+__device__ __attribute__((aligned(256))) unsigned g_round_done[kRoundSlots][8];  // one copy per translation unit and device
+
+// Host bookkeeping of the counter sets of one device (per translation unit, like the array).
+struct RoundHost {
+  unsigned* dev_ptr = nullptr;  // address of this device's copy of g_round_done
+  int cus_per_xcd = 0;          // 0 = alignment unavailable on this device (not 8 XCDs' worth of CUs)
+  unsigned next = 0;            // next slot
+  unsigned base[kRoundSlots][8] = {};
+};
 
 // Launch `kshort` (skv <= 2048) or `klong` over the first `nwg` of the nqb * heads workgroups
 // (head-major order) with `threads` threads each, with round alignment when a head's K/V outgrows
 // an XCD's L2 (4 MiB) and there are many rounds.
 template <class KS, class KL>
 int launch_with_rounds(KS kshort, KL klong, int threads, const lx2v_attn::AttnParams& p, int64_t nwg, hipStream_t st, const char* what) {
-  RoundSync rs{nullptr, 32};
-  static const bool sync_off = [] { const char* e = getenv("LX2V_ATTN_ROUND_SYNC"); return e && atoi(e) == 0; }();
-  if (!sync_off && (int64_t)p.skv * lx2v_attn::HD * 4 > (8 << 20)) {
+  RoundSync rs{};
+  rs.done = nullptr;
+  rs.cus_per_xcd = 32;
+  static std::mutex mu;
+  static RoundHost host[64];
+  RoundHost* h = nullptr;
+  unsigned slot = 0;
+  if (lx2v_options().attn_round_sync != 0 && (int64_t)p.skv * lx2v_attn::HD * 4 > (8 << 20)) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { lx2v_set_error("%s: hipGetDevice failed", what); return LX2V_EHIP; }
-    static unsigned* counters[64];   // per device: address of that device's copy of g_round_done
-    static int cus[64];
-    if (counters[dev] == nullptr) {
-      hipDeviceProp_t prop;
-      if (hipGetSymbolAddress((void**)&counters[dev], HIP_SYMBOL(g_round_done)) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-        counters[dev] = nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    h = &host[dev];
+    if (h->dev_ptr == nullptr) {
+      int cus = 0;
+      if (hipGetSymbolAddress((void**)&h->dev_ptr, HIP_SYMBOL(g_round_done)) != hipSuccess ||
+          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+        h->dev_ptr = nullptr;
         lx2v_set_error("%s: round counters unavailable", what);
         return LX2V_EHIP;
       }
-      cus[dev] = prop.multiProcessorCount / 8;
+      h->cus_per_xcd = (cus >= 64 && cus % 8 == 0) ? cus / 8 : 0;
     }
-    if (cus[dev] > 0 && nwg > 16 * (int64_t)cus[dev]) {
-      if (hipMemsetAsync(counters[dev], 0, 8 * sizeof(unsigned), st) != hipSuccess) { lx2v_set_error("%s: counter reset failed", what); return LX2V_EHIP; }
-      rs.done = counters[dev];
-      rs.cus_per_xcd = cus[dev];
+    if (h->cus_per_xcd > 0 && nwg > 16 * (int64_t)h->cus_per_xcd) {
+      slot = h->next++ % kRoundSlots;
+      rs.done = h->dev_ptr + slot * 8;
+      rs.cus_per_xcd = h->cus_per_xcd;
+      for (int x = 0; x < 8; ++x) {
+        rs.base[x] = h->base[slot][x];
+        h->base[slot][x] += (unsigned)(nwg / 8 + (x < nwg % 8 ? 1 : 0));
+      }
+    } else {
+      h = nullptr;
     }
   }
   if (p.skv <= 2048) hipLaunchKernelGGL(kshort, dim3((unsigned)nwg), dim3(threads), 0, st, p, rs);
   else hipLaunchKernelGGL(klong, dim3((unsigned)nwg), dim3(threads), 0, st, p, rs);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    if (h != nullptr) {  // nothing ran: the counters keep their old values
+      std::lock_guard<std::mutex> lock(mu);
+      for (int x = 0; x < 8; ++x) h->base[slot][x] = rs.base[x];
+    }
+    lx2v_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return LX2V_EHIP;
+  }
   return LX2V_OK;
 }
 

@@ -57,6 +57,19 @@ LX2V_DEVICE float gelu_tanh(float x) {
 // ---- host side -------------------------------------------------------------------------------
 void lx2v_set_error(const char* fmt, ...);
 
+// Kernel-selection switches (A/B and test knobs).  Read from the environment once, on first use;
+// lx2v_set_option() overrides them afterwards.  Launchers read this struct, never the environment.
+struct Lx2vOptions {
+  int attn_kernel;      // LX2V_ATTN_KERNEL=x16|w4|w8 -> 16 (default), 4, 8
+  int attn_qb;          // LX2V_ATTN_QB=4|5 fixes the query blocks per wave of the x16 kernel; 0 = by cost
+  int attn_tail;        // LX2V_ATTN_TAIL=0: no second launch for a sparse last round
+  int attn_round_sync;  // LX2V_ATTN_ROUND_SYNC=0: no round alignment (a locality hint: same results)
+  int attn_variant;     // LX2V_ATTN_VARIANT=0: 8-wave kernel without pipelined K-fragment reads
+  int gemm_kernel;      // LX2V_GEMM_KERNEL=simple|pingpong -> 1 | 2; 0 = each GEMM's default (bf16: ping-pong, fp8: simple)
+  int gemm_persistent;  // LX2V_GEMM_PERSISTENT=0: one workgroup per tile instead of the persistent tile loop
+};
+const Lx2vOptions& lx2v_options();
+
 #define LX2V_REQUIRE(cond, code, ...)  \
   do {                                 \
     if (!(cond)) {                     \

@@ -423,9 +423,8 @@ extern "C" int lx2v_gemm_fp8(const uint8_t* A, int64_t lda, const float* a_scale
   hipStream_t st = (hipStream_t)stream;
   // The one-barrier-per-K-tile schedule is the default here: at 14B shapes it measured 2.0-2.24 PFLOP/s
   // against 1.87-2.11 for the ping-pong schedule (which wins by 10 % on the bf16 GEMM).
-  // LX2V_GEMM_KERNEL=pingpong selects the latter (A/B switch, read per call).
-  const char* sched = getenv("LX2V_GEMM_KERNEL");
-  const bool simple = !(sched != nullptr && strcmp(sched, "pingpong") == 0);
+  // Option gemm_kernel = 2 selects the latter (A/B switch).
+  const bool simple = lx2v_options().gemm_kernel != 2;
   if (simple || K < 2 * BK) {
     switch (epilogue) {
       case LX2V_EPI_NONE: hipLaunchKernelGGL(gemm_fp8_kernel<LX2V_EPI_NONE>, grid, block, 0, st, p); break;

@@ -62,7 +62,7 @@ def test_gemm_fp8_matches_quantised_domain_product(cuda, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(3000, 2048, 2048, "none"), (1111, 1536, 8960, "gelu"), (2000, 5120, 5120, "resid"), (700, 512, 384, "none")])
-def test_gemm_fp8_schedules_agree_bitwise(cuda, M, N, K, epi, monkeypatch):
+def test_gemm_fp8_schedules_agree_bitwise(cuda, M, N, K, epi, options):
     """The ping-pong schedule accumulates in the same order as the one-barrier schedule: bit-identical
     results, across repeated launches with other traffic in flight."""
     aq, a_s = R.quant_fp8_rowwise(_rand((M, K), 60))
@@ -79,9 +79,9 @@ def test_gemm_fp8_schedules_agree_bitwise(cuda, M, N, K, epi, monkeypatch):
             return hip.gemm_fp8(*args, epilogue=hip.EPI_RESIDUAL, resid=resid.clone(), gate=gate)
         return hip.gemm_fp8(*args)
 
-    monkeypatch.delenv("LX2V_GEMM_KERNEL", raising=False)
+    options(gemm_kernel=0)
     ref = run()
-    monkeypatch.setenv("LX2V_GEMM_KERNEL", "pingpong")
+    options(gemm_kernel=2)  # the ping-pong schedule
     noise = torch.empty(64 << 20, dtype=torch.uint8, device=cuda)
     for i in range(6):
         if i % 2:
