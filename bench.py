@@ -67,18 +67,22 @@ def block_flops(S, D, H, F, T=TEXT_LEN):
     return self_attn, cross, gemm
 
 
+TRAFFIC_FILES = ("r02_attn_traffic.json", "r01_attn_traffic.json")  # newest first
+
+
 def measured_traffic(S, heads_local):
-    """HBM-side bytes per self-attention launch from the committed PMC collection (profiles/),
-    or None when no collection matches this launch shape."""
-    path = os.path.join(ROOT, "profiles", "r01_attn_traffic.json")
-    try:
-        rec = json.load(open(path))
-    except OSError:
-        return None
-    w = rec.get("workload", {})
-    if w.get("tokens") == S and w.get("heads") == heads_local:
-        return rec.get("traffic_bytes_per_launch")
-    return None
+    """(bytes, source): HBM-side bytes per self-attention launch from the newest committed PMC
+    collection under profiles/ that matches this launch shape (counters cannot be read from inside
+    this process: they need their own rocprofv3 pass), or (None, None)."""
+    for name in TRAFFIC_FILES:
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except OSError:
+            continue
+        w = rec.get("workload", {})
+        if w.get("tokens") == S and w.get("heads") == heads_local:
+            return rec.get("traffic_bytes_per_launch"), "profiles/" + name + " (separate rocprofv3 --pmc pass of this workload, not this run)"
+    return None, None
 
 
 def default_layout(n):
@@ -154,27 +158,43 @@ class AttnTimer:
         return sum(a.elapsed_time(b) for a, b in self.events)
 
 
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(D, H, F, full_S, layers, threads):
-    """fp32 oracle block (torch_sdpa-equivalent) on the host cores, on a bounded sample: one block
-    of the same architecture at a reduced token count; extrapolated to the full step by FLOPs."""
+    """fp32 oracle block (the reference's torch_sdpa + Default-matmul path restated) on the host
+    cores, on a bounded sample: one block of the same architecture at a reduced token count, one
+    warm-up run and three timed runs (median); extrapolated to the full step by FLOPs."""
     from oracle import wan_block_ref as R
 
     torch.set_num_threads(threads)
-    grid = (5, 45, 80) if full_S > 20000 else (4, 30, 52)  # ~10-20 s of CPU work on 16 threads
+    grid = (3, 45, 80) if full_S > 40000 else (3, 30, 52)  # a few seconds per run on 16 threads
     S = grid[0] * grid[1] * grid[2]
     w = R.make_block_weights(D, F, seed=0)
     x, context, embed0, _ = R.make_inputs(S, D, TEXT_LEN, seed=0)
     cs = R.build_cos_sin(grid, D // H)
+    times = []
     with torch.no_grad():
-        t0 = time.time()
-        R.block_forward(x, embed0, context, w, cs, H)
-        dt = time.time() - t0
+        for run in range(4):
+            t0 = time.time()
+            R.block_forward(x, embed0, context, w, cs, H)
+            if run > 0:
+                times.append(time.time() - t0)
+    dt = sorted(times)[1]
     sample_flops = sum(block_flops(S, D, H, F))
     rate = sample_flops / dt  # FLOP/s on this host
     full_flops = sum(block_flops(full_S, D, H, F)) * layers * 2
     return {
-        "value": full_flops / rate, "unit": "s/denoise-step", "cores": threads, "kind": "port",
-        "sample": f"one fp32 oracle block at S={S} tokens ({grid[0]}x{grid[1]}x{grid[2]}), D={D}, took {dt:.1f} s = {rate / 1e12:.3f} TFLOP/s; "
+        "value": full_flops / rate, "unit": "s/denoise-step", "cores": threads, "kind": "port", "cpu_model": cpu_model_name(),
+        "runs_s": [round(t, 3) for t in times],
+        "sample": f"one fp32 oracle block at S={S} tokens ({grid[0]}x{grid[1]}x{grid[2]}), D={D}: 1 warm-up + 3 timed runs, median {dt:.2f} s = {rate / 1e12:.3f} TFLOP/s on {threads} threads; "
                   f"extrapolated by algorithmic FLOPs to {layers} blocks x 2 CFG passes at S={full_S}",
     }
 
@@ -344,28 +364,11 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-            # rehearsal only: gloo's CUDA path can hang when a collective is issued behind pending GPU
-            # work of several processes sharing one GPU; drain the stream first
-            # (and run "async" collectives synchronously: several outstanding gloo operations on CUDA
-            # tensors of processes sharing one GPU deadlock)
-            class _Done:
-                def wait(self):
-                    return True
+            # rehearsal only: ranks that share one GPU hand gloo host copies (gloo's own CUDA path
+            # stalls there, tools/probe_gloo_shared_gpu.py)
+            from lightx2v_amd import comm
 
-            for name in ("all_to_all_single", "all_gather", "all_reduce"):
-                def _synced(*a, _fn=getattr(dist, name), _name=name, **kw):
-                    was_async = kw.pop("async_op", False)
-                    torch.cuda.synchronize()
-                    if _name == "all_to_all_single":  # gloo's CUDA path also stalls on offset views: use whole tensors
-                        dst, src = a[0], a[1]
-                        tmp = torch.empty(dst.shape, dtype=dst.dtype, device=dst.device)
-                        out = _fn(tmp, src.clone(), *a[2:], **kw)
-                        dst.copy_(tmp)
-                        torch.cuda.synchronize()
-                    else:
-                        out = _fn(*a, **kw)
-                    return _Done() if was_async else out
-                setattr(dist, name, _synced)
+            comm.set_transport(comm.HostStagedTransport())
     cfg_p, seq_p = default_layout(world) if args.layout is None else tuple(int(v) for v in args.layout.lower().split("x"))
     assert cfg_p * seq_p == world and cfg_p in (1, 2)
 
@@ -454,6 +457,8 @@ def main():
         step()
     for t in timers:
         t.enabled = True
+    if world > 1:
+        ulysses.COMM_TIMER.enable()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -474,6 +479,8 @@ def main():
     sa, ca, ge = block_flops(S, D, H, F)
     step_flops = (sa + ca + ge) * layers * 2
 
+    traffic, traffic_source = measured_traffic(S_pad, H // seq_p) if (args.attn == "bf16" and n_launches == layers * 2 * args.steps // cfg_p) else (None, None)
+    exposed_ms = ulysses.COMM_TIMER.total_ms() / args.steps if world > 1 else 0.0
     if rank == 0:
         line = {
             "metric": "s/denoise-step Wan2.1-T2V-14B 720p81f" if (args.model, args.res, args.linear, args.attn) == ("wan2.1-t2v-14b", "720p", "bf16", "bf16") else f"s/denoise-step {args.model} {args.res}81f" + arithmetic_label(args)[1],
@@ -486,10 +493,12 @@ def main():
                        "parallelism": f"cfg_p{cfg_p} x seq_p{seq_p} (ulysses)", "tokens": S, "dim": D, "heads": H, "ffn_dim": F, "layers": layers},
             "step_tflops": step_flops / 1e12,
             "achieved_tflops_per_gpu": step_flops / s_per_step / 1e12 / world,
+            # rank 0's compute stream blocked in waits for the Ulysses exchanges, per step (events around each wait)
+            "exposed_comm_ms_per_step": exposed_ms, "ulysses_chunks": int(os.environ.get("LX2V_ULYSSES_CHUNKS", "2")),
             "roofline": {"kernel": "attn_fwd_x16_kernel (self-attention: main launch + 64-row tail launch)" if args.attn == "bf16" else "attn_fwd_fp8_kernel<false> + quantisation pre-pass (self-attention)",
                          "bound": "mfma", "achieved": achieved, "peak": attn_peak(args),
                          "unit": "TFLOP/s", "frac": achieved / attn_peak(args),
-                         "traffic": measured_traffic(S_pad, H // seq_p) if (args.attn == "bf16" and n_launches == layers * 2 * args.steps // cfg_p) else None,
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "launch_ms": attn_ms, "flops_per_launch": attn_flops, "launches_timed": n_launches},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -26,10 +26,22 @@ extern "C" {
 #define LX2V_EUNSUP (-2)   /* valid request outside what the kernels are built for */
 #define LX2V_EHIP (-3)     /* a HIP runtime call failed (launch error) */
 
-/* ABI version of this header (bumped when a signature changes). */
+/* ABI version of this header (bumped when a signature changes or an entry point is added). */
 int lx2v_abi_version(void);
 /* Thread-local text of the last non-zero return. Host pointer, valid until the next call. */
 const char* lx2v_last_error(void);
+
+/* ---- kernel-selection switches -------------------------------------------------------------
+ * Named integer options, initialised once from the environment (LX2V_ATTN_KERNEL, LX2V_ATTN_QB,
+ * LX2V_ATTN_TAIL, LX2V_ATTN_ROUND_SYNC, LX2V_ATTN_VARIANT, LX2V_GEMM_KERNEL, LX2V_GEMM_PERSISTENT)
+ * and changeable at run time; launches read them, never the environment.  Names: "attn_kernel"
+ * (16 | 4 | 8), "attn_qb" (0 | 4 | 5), "attn_tail", "attn_round_sync", "attn_variant" (0 | 1),
+ * "gemm_kernel" (0 default | 1 simple | 2 ping-pong), "gemm_persistent" (0 | 1).  Every setting
+ * computes the same function; they exist for A/B timing and for tests.  Not to be changed while
+ * another thread launches.  Stands where the reference selects a backend by registry name
+ * (lightx2v/utils/registry_factory.py:1-56): these choose among kernels behind ONE name. */
+int lx2v_set_option(const char* name, int value);
+int lx2v_get_option(const char* name, int* value);
 
 /* ---- LayerNorm (+ optional affine) (+ optional AdaLN modulate), one pass over HBM ----------
  * out[r,:] = (LN(x[r,:]) * ln_w + ln_b) * (1 + scale) + shift       (fp32 statistics)
@@ -78,17 +90,25 @@ int lx2v_gelu_tanh_bf16(const uint16_t* x, uint16_t* out, int64_t n, void* strea
  *            LX2V_EPI_GELU_TANH : C = gelu_tanh(acc + bias)
  *            LX2V_EPI_RESIDUAL  : C = resid + (acc + bias) * gate   (gate fp32 [N] or NULL => 1;
  *                                  resid [M,N] row stride ldr; resid may alias C)
- * A may be split along K into segments of a_kseg columns that sit a_kseg_stride ELEMENTS apart
- * (segment s of row m starts at A + s*a_kseg_stride + m*lda); pass a_kseg = 0 for a plain
- * matrix.  This lets the output projection read the sequence-parallel attention result
- * [source_rank][S/N][H/N*d] without a gather copy.
- * Requires K % 64 == 0, N % 16 == 0, 16-byte aligned rows.
+ * A's columns may be stored as segments (`kseg` != NULL): `seg` columns each, segment s of row m
+ * starting at A + s*stride + m*lda; from K column `split` on (0 = no second region) the segments are
+ * `seg2` columns wide and segment t of that region starts at A + base2 + t*stride2 + m*lda2.  Pass
+ * kseg = NULL for a plain matrix.  This lets the output projection read the sequence-parallel
+ * attention result ([source rank][S/N][heads*d] per head chunk, chunks of two widths) without a
+ * gather copy.  The struct is read before the call returns.
+ * Requires K % 64 == 0, N % 8 == 0, 16-byte aligned rows.
  * Replaces MMWeight.apply (torch.addmm)  lightx2v/common/ops/mm/mm_weight.py:163-170, with the
  * residual/GELU steps of transformer_infer.py:209-213,279,305,312-316 fused as epilogues. */
+typedef struct lx2v_kseg {
+  int64_t seg, stride;          /* region 1: columns per segment, elements between segment starts */
+  int64_t split;                /* first K column of region 2; 0 = one region */
+  int64_t seg2, stride2, base2; /* region 2: segment width, stride, element offset of its first segment */
+  int64_t lda2;                 /* region 2: row stride in elements */
+} lx2v_kseg;
 #define LX2V_EPI_NONE 0
 #define LX2V_EPI_GELU_TANH 1
 #define LX2V_EPI_RESIDUAL 2
-int lx2v_gemm_bf16(const uint16_t* A, int64_t lda, int64_t a_kseg, int64_t a_kseg_stride,
+int lx2v_gemm_bf16(const uint16_t* A, int64_t lda, const lx2v_kseg* kseg,
                    const uint16_t* W, int64_t ldw, const float* bias,
                    uint16_t* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
                    const uint16_t* resid, int64_t ldr, const float* gate, void* stream);

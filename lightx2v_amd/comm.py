@@ -1,0 +1,96 @@
+"""The collectives of the sequence-parallel / CFG-parallel paths, behind one replaceable transport.
+
+Production transport: `torch.distributed` as it is -- backend "nccl" is RCCL on ROCm, one process
+per GPU, collectives run on RCCL's own stream over xGMI.  The reference calls the same functions
+directly (lightx2v/common/ops/attn/utils/all2all.py:29-39,70-81, lightx2v/models/networks/wan/model.py:412-427,493-499).
+
+`HostStagedTransport` exists for functional runs of N ranks that share ONE GPU (tests, rehearsals):
+RCCL refuses two ranks on one device, and gloo's own CUDA path stalls there -- a bare loop of
+`dist.all_to_all_single` on CUDA tensors between two processes sharing a GPU parks both ranks
+inside the call after a handful of iterations (tools/probe_gloo_shared_gpu.py, scenario A; nothing
+of this package is involved).  The staged transport hands gloo host tensors only: the payload is
+copied to the host when the collective is issued, the exchange itself stays asynchronous (several
+may be outstanding, in issue order, like on RCCL), and the result is copied to the GPU on `wait()`.
+"""
+
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class DistTransport:
+    """torch.distributed, unchanged."""
+
+    name = "torch.distributed"
+
+    def all_to_all_single(self, output: torch.Tensor, input: torch.Tensor, group=None, async_op: bool = False):
+        return dist.all_to_all_single(output, input, group=group, async_op=async_op)
+
+    def all_gather(self, outputs: List[torch.Tensor], input: torch.Tensor, group=None, async_op: bool = False):
+        return dist.all_gather(outputs, input, group=group, async_op=async_op)
+
+
+class _StagedWork:
+    def __init__(self, work, finish):
+        self._work, self._finish = work, finish
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._finish()
+            self._work = None
+        return True
+
+
+class HostStagedTransport(DistTransport):
+    """Collectives on host copies (see the module docstring).  Payloads travel as bytes, so every
+    dtype the GPU path uses (bf16, e4m3 bytes, fp32 scales) goes through the same gloo call."""
+
+    name = "host-staged gloo"
+
+    def all_to_all_single(self, output, input, group=None, async_op=False):
+        world = dist.get_world_size(group)
+        if input.numel() % world != 0 or output.numel() != input.numel() or not output.is_contiguous():
+            raise ValueError("host-staged all_to_all_single: equal splits of a contiguous output are supported")
+        src = input.contiguous().reshape(world, -1).view(torch.uint8).cpu()  # waits for the producer kernels
+        dst = torch.empty_like(src)
+        work = dist.all_to_all_single(dst, src, group=group, async_op=True)
+        staged = _StagedWork(work, lambda: output.view(torch.uint8).reshape(-1).copy_(dst.reshape(-1)))
+        if async_op:
+            return staged
+        staged.wait()
+        return None
+
+    def all_gather(self, outputs, input, group=None, async_op=False):
+        src = input.contiguous().reshape(-1).view(torch.uint8).cpu()
+        parts = [torch.empty_like(src) for _ in outputs]
+        work = dist.all_gather(parts, src, group=group, async_op=True)
+
+        def finish():
+            for o, p in zip(outputs, parts):
+                if not o.is_contiguous():
+                    raise ValueError("host-staged all_gather: outputs must be contiguous")
+                o.view(torch.uint8).reshape(-1).copy_(p)
+
+        staged = _StagedWork(work, finish)
+        if async_op:
+            return staged
+        staged.wait()
+        return None
+
+
+_transport: DistTransport = DistTransport()
+
+
+def transport() -> DistTransport:
+    return _transport
+
+
+def set_transport(t: Optional[DistTransport]) -> DistTransport:
+    """Install `t` (None = torch.distributed) for this process; returns the previous transport."""
+    global _transport
+    old, _transport = _transport, (t if t is not None else DistTransport())
+    return old

@@ -38,6 +38,7 @@ struct GemmParams {
   const float* gate;
   int64_t lda, ldw, ldc, ldr;
   int64_t a_kseg, a_kseg_stride;  // a_kseg == 0: plain matrix
+  int64_t a_split, a_kseg2, a_kseg2_stride, a_base2, lda2;  // a_split > 0: from K column a_split on, segments of a_kseg2 columns starting at A + a_base2, row stride lda2
   int M, N, K;
   int tiles_m, tiles_n;
 };
@@ -48,6 +49,35 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 LX2V_DEVICE void glds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)l, 16, 0, 0);
 }
+
+// Position of a K-tile inside A when A's columns are stored as segments (see lx2v_kseg): `koff` is
+// the element offset of the tile from the row start; advance() moves one K-tile on.  All fields are
+// wave-uniform.
+struct ACursor {
+  int64_t koff = 0, within = 0, kpos = 0, seg, stride;
+  LX2V_DEVICE explicit ACursor(const GemmParams& p) : seg(p.a_kseg), stride(p.a_kseg_stride) {}
+  // Returns true when the cursor has just entered region 2 (the caller then switches its per-lane
+  // row offsets from lda to lda2).
+  LX2V_DEVICE bool advance(const GemmParams& p) {
+    koff += BK;
+    if (p.a_kseg != 0) {
+      within += BK;
+      kpos += BK;
+      if (kpos == p.a_split) {  // never true for a_split == 0 (kpos >= BK)
+        koff = p.a_base2;
+        within = 0;
+        seg = p.a_kseg2;
+        stride = p.a_kseg2_stride;
+        return true;
+      }
+      if (within == seg) {
+        within = 0;
+        koff += stride - seg;
+      }
+    }
+    return false;
+  }
+};
 
 // Bijective remap so that blocks sharing an XCD (same blockIdx % 8) get a contiguous run of tiles.
 LX2V_DEVICE int xcd_remap(int bid, int nwg) {
@@ -136,6 +166,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const GemmParams p)
   // LDS byte offset o = i*8192 + tid*16 -> row = o >> 7, physical chunk = (o >> 4) & 7.
   const uint16_t* a_src[4];
   const uint16_t* w_src[4];
+  int a_row[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int o = i * 8192 + tid * 16;
@@ -145,25 +176,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const GemmParams p)
     const int wr = min(n0 + row, p.N - 1);
     a_src[i] = p.A + (int64_t)ar * p.lda + chunk * 8;
     w_src[i] = p.W + (int64_t)wr * p.ldw + chunk * 8;
+    a_row[i] = ar;
   }
-  int64_t a_koff = 0;   // element offset of the current K-tile inside A (segment aware)
-  int64_t a_within = 0;
+  ACursor a_cur(p);  // the K-tile staged next
 
   auto stage = [&](int s, int kt) {
     char* la = lds + s * 2 * TILE_BYTES + wid * 1024;
     char* lw = la + TILE_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(a_src[i] + a_koff, la + i * 8192);
+    for (int i = 0; i < 4; ++i) glds16(a_src[i] + a_cur.koff, la + i * 8192);
 #pragma unroll
     for (int i = 0; i < 4; ++i) glds16(w_src[i] + (int64_t)kt * BK, lw + i * 8192);
-    // advance A's K offset to the next tile
-    a_koff += BK;
-    if (p.a_kseg != 0) {
-      a_within += BK;
-      if (a_within == p.a_kseg) {
-        a_within = 0;
-        a_koff += p.a_kseg_stride - p.a_kseg;
-      }
+    if (a_cur.advance(p)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a_src[i] += (int64_t)a_row[i] * (p.lda2 - p.lda);
     }
   };
 
@@ -263,8 +289,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_pp_kernel(const GemmParams
   // Sources are a wave-uniform base (tile origin + K offset, scalar registers) plus a per-lane
   // 32-bit byte offset inside the tile's row panel.
   uint32_t soff[4][2];
+  uint32_t soff2[2][2];  // soff of the A units (0: Am0, 1: Am1) under region 2's row stride
   int dst[4][2];  // LDS byte offset of the wave's first lane, inside buffer 0
-  const char* a_base = reinterpret_cast<const char*>(p.A + (int64_t)m0 * p.lda);
+  const char* a_base[2] = {reinterpret_cast<const char*>(p.A + (int64_t)m0 * p.lda), nullptr};  // row panel origin for Am0 / Am1
+  a_base[1] = a_base[0];
   const char* w_base = reinterpret_cast<const char*>(p.W + (int64_t)n0 * p.ldw);
 #pragma unroll
   for (int U = 0; U < 4; ++U)
@@ -277,26 +305,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_pp_kernel(const GemmParams
       const int chunk = (lane & 7) ^ ((row >> 1) & 7);
       const int rr = is_a ? min(row, p.M - 1 - m0) : min(row, p.N - 1 - n0);  // rows past the edge re-read the last one
       soff[U][i] = (uint32_t)((int64_t)rr * (is_a ? p.lda : p.ldw) * 2 + chunk * 16);
+      if (is_a) soff2[U == 3][i] = (uint32_t)((int64_t)rr * p.lda2 * 2 + chunk * 16);
       dst[U][i] = (is_a ? 0 : W_BASE) + row0 * 128;
     }
-  // element offset of a K-tile inside A (segment aware), advanced one tile at a time
-  int64_t a_koff_issue = 0, a_within = 0;  // offset of the tile whose Am0 is issued next
-  int64_t a_koff_am1 = 0;                  // offset of the tile whose Am1 is issued next
-  auto a_advance = [&](int64_t& koff, int64_t& within) {
-    koff += BK;
-    if (p.a_kseg != 0) {
-      within += BK;
-      if (within == p.a_kseg) {
-        within = 0;
-        koff += p.a_kseg_stride - p.a_kseg;
-      }
-    }
+  auto enter_region2 = [&](int U) {  // U = 0 (Am0) or 3 (Am1): the unit's cursor now gives offsets of region 2
+    a_base[U == 3] = reinterpret_cast<const char*>(p.A + (int64_t)m0 * p.lda2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) soff[U][i] = soff2[U == 3][i];
   };
-  int64_t am1_within = 0;
+  ACursor a_issue(p);  // the tile whose Am0 is issued next
+  ACursor a_am1(p);    // the tile whose Am1 is issued next
 
   auto issue = [&](int U, int buf, int64_t koff) {
     if (GEMM_ABL & 2) return;
-    const char* base = ((U == 0 || U == 3) ? a_base : w_base) + koff * 2;
+    const char* base = (U == 0 ? a_base[0] : U == 3 ? a_base[1] : w_base) + koff * 2;
 #pragma unroll
     for (int i = 0; i < 2; ++i) glds16(base + soff[U][i], lds + dst[U][i] + buf * A_BUF);
   };
@@ -321,15 +343,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_pp_kernel(const GemmParams
   const int nk = p.K / BK;  // >= 2 (checked by the launcher)
 
   // ---- prologue: Am0(0) Bn0(0) Bn1(0) Am1(0) Am0(1) Bn0(1) ----
-  issue(0, 0, a_koff_issue);
+  issue(0, 0, a_issue.koff);
   issue(1, 0, 0);
   issue(2, 0, 0);
-  issue(3, 0, a_koff_am1);
-  a_advance(a_koff_issue, a_within);
-  a_advance(a_koff_am1, am1_within);
-  issue(0, 1, a_koff_issue);
+  issue(3, 0, a_am1.koff);
+  if (a_issue.advance(p)) enter_region2(0);
+  if (a_am1.advance(p)) enter_region2(3);
+  issue(0, 1, a_issue.koff);
   issue(1, 1, BK);
-  a_advance(a_koff_issue, a_within);  // now the offset of tile 2
+  if (a_issue.advance(p)) enter_region2(0);  // now at tile 2
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind
@@ -374,7 +396,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_pp_kernel(const GemmParams
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) b1[nt][ks] = *reinterpret_cast<const bf16x8*>(base + w_rd[ks] + RD + (nt + 2) * 2048);
-    if (KIND != TILE_LAST) issue(3, BUF ^ 1, a_koff_am1);
+    if (KIND != TILE_LAST) issue(3, BUF ^ 1, a_am1.koff);
     if (KIND == TILE_LAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -390,13 +412,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_pp_kernel(const GemmParams
     if (!(GEMM_ABL & 8)) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    a_advance(a_koff_am1, am1_within);
+    if (a_am1.advance(p)) enter_region2(3);
     // ---- phase 3: quadrant (m1, n1) ----
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) af[mt][ks] = *reinterpret_cast<const bf16x8*>(base + a_rd[ks] + RD + (mt + 4) * 2048);
-    if (KIND == TILE_FULL) issue(0, BUF, a_koff_issue);
+    if (KIND == TILE_FULL) issue(0, BUF, a_issue.koff);
     if (KIND == TILE_FULL) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (KIND == TILE_PENULT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -428,7 +450,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_pp_kernel(const GemmParams
     if (!(GEMM_ABL & 8)) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    if (KIND == TILE_FULL) a_advance(a_koff_issue, a_within);
+    if (KIND == TILE_FULL && a_issue.advance(p)) enter_region2(0);
   };
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
@@ -452,7 +474,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_pp_kernel(const GemmParams
 
 }  // namespace
 
-extern "C" int lx2v_gemm_bf16(const uint16_t* A, int64_t lda, int64_t a_kseg, int64_t a_kseg_stride,
+extern "C" int lx2v_gemm_bf16(const uint16_t* A, int64_t lda, const lx2v_kseg* kseg,
                               const uint16_t* W, int64_t ldw, const float* bias,
                               uint16_t* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
                               const uint16_t* resid, int64_t ldr, const float* gate, void* stream) {
@@ -465,9 +487,17 @@ extern "C" int lx2v_gemm_bf16(const uint16_t* A, int64_t lda, int64_t a_kseg, in
   LX2V_REQUIRE(ldw >= K && ldc >= N, LX2V_EINVAL, "gemm: ldw/ldc smaller than the row length");
   LX2V_REQUIRE(lx2v_aligned16(A) && lx2v_aligned16(W) && lx2v_aligned16(C), LX2V_EINVAL, "gemm: tensors must be 16-byte aligned");
   LX2V_REQUIRE(bias == nullptr || lx2v_aligned16(bias), LX2V_EINVAL, "gemm: bias must be 16-byte aligned");
-  if (a_kseg != 0) {
-    LX2V_REQUIRE(a_kseg > 0 && a_kseg % BK == 0 && K % a_kseg == 0, LX2V_EINVAL, "gemm: a_kseg=%lld must be a multiple of %d dividing K", (long long)a_kseg, BK);
-    LX2V_REQUIRE(a_kseg_stride % 8 == 0 && lda >= a_kseg, LX2V_EINVAL, "gemm: segmented A needs lda >= a_kseg and an 8-element aligned segment stride");
+  lx2v_kseg ks = {0, 0, 0, 0, 0, 0, 0};
+  if (kseg != nullptr) ks = *kseg;
+  if (ks.seg != 0) {
+    const int64_t k1 = ks.split > 0 ? ks.split : K;  // columns of region 1
+    LX2V_REQUIRE(ks.split >= 0 && ks.split < K, LX2V_EINVAL, "gemm: kseg.split=%lld outside [0, K)", (long long)ks.split);
+    LX2V_REQUIRE(ks.seg > 0 && ks.seg % BK == 0 && k1 % ks.seg == 0, LX2V_EINVAL, "gemm: kseg.seg=%lld must be a multiple of %d dividing its region of %lld columns", (long long)ks.seg, BK, (long long)k1);
+    LX2V_REQUIRE(ks.stride % 8 == 0 && lda >= ks.seg, LX2V_EINVAL, "gemm: segmented A needs lda >= kseg.seg and an 8-element aligned segment stride");
+    if (ks.split > 0) {
+      LX2V_REQUIRE(ks.seg2 > 0 && ks.seg2 % BK == 0 && (K - ks.split) % ks.seg2 == 0, LX2V_EINVAL, "gemm: kseg.seg2=%lld must be a multiple of %d dividing the %lld columns after the split", (long long)ks.seg2, BK, (long long)(K - ks.split));
+      LX2V_REQUIRE(ks.stride2 % 8 == 0 && ks.base2 % 8 == 0 && ks.lda2 % 8 == 0 && ks.lda2 >= ks.seg2, LX2V_EINVAL, "gemm: region 2 needs lda2 >= kseg.seg2 and 8-element aligned lda2, stride and base");
+    }
   } else {
     LX2V_REQUIRE(lda >= K, LX2V_EINVAL, "gemm: lda smaller than K");
   }
@@ -481,7 +511,8 @@ extern "C" int lx2v_gemm_bf16(const uint16_t* A, int64_t lda, int64_t a_kseg, in
   GemmParams p;
   p.A = A; p.W = W; p.bias = bias; p.C = C; p.resid = resid; p.gate = gate;
   p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
-  p.a_kseg = a_kseg; p.a_kseg_stride = a_kseg_stride;
+  p.a_kseg = ks.seg; p.a_kseg_stride = ks.stride;
+  p.a_split = ks.seg != 0 ? ks.split : 0; p.a_kseg2 = ks.seg2; p.a_kseg2_stride = ks.stride2; p.a_base2 = ks.base2; p.lda2 = ks.split > 0 ? ks.lda2 : lda;
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
   p.tiles_m = (int)((M + BM - 1) / BM);
   p.tiles_n = (int)((N + BN - 1) / BN);
@@ -489,8 +520,7 @@ extern "C" int lx2v_gemm_bf16(const uint16_t* A, int64_t lda, int64_t a_kseg, in
   LX2V_REQUIRE(nwg < (1LL << 31), LX2V_EUNSUP, "gemm: too many tiles");
   const dim3 grid((unsigned)nwg), block(NTHREADS);
   hipStream_t st = (hipStream_t)stream;
-  const char* sched = getenv("LX2V_GEMM_KERNEL");  // "simple": the one-barrier-per-K-tile schedule (A/B switch, read per call)
-  const bool simple = sched != nullptr && strcmp(sched, "simple") == 0;
+  const bool simple = lx2v_options().gemm_kernel == 1;  // the one-barrier-per-K-tile schedule (A/B switch)
   if (simple || K < 2 * BK) {
     switch (epilogue) {
       case LX2V_EPI_NONE: hipLaunchKernelGGL(gemm_bf16_kernel<LX2V_EPI_NONE>, grid, block, 0, st, p); break;

@@ -181,12 +181,12 @@ static void bench_gemm(int M, int N, int K, int epi, int iters) {
   HIPCHK(hipMalloc(&gate, N * 4));
   HIPCHK(hipMemcpy(bias, hb.data(), N * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(gate, hg.data(), N * 4, hipMemcpyHostToDevice));
-  auto run = [&] { LXCHK(lx2v_gemm_bf16(a, K, 0, 0, w, K, bias, c, N, M, N, K, epi, epi == 2 ? c : nullptr, N, epi == 2 ? gate : nullptr, nullptr)); };
+  auto run = [&] { LXCHK(lx2v_gemm_bf16(a, K, nullptr, w, K, bias, c, N, M, N, K, epi, epi == 2 ? c : nullptr, N, epi == 2 ? gate : nullptr, nullptr)); };
   const float ms = time_ms(run, iters);
   const double flops = 2.0 * M * (double)N * K;
   printf("gemm  M=%d N=%d K=%d epi=%d : %.3f ms  %.1f TFLOP/s (%.1f%% of 2500)\n", M, N, K, epi, ms, flops / ms * 1e-9, flops / ms * 1e-9 / 25.0);
   if (epi != 2) {
-    LXCHK(lx2v_gemm_bf16(a, K, 0, 0, w, K, bias, c, N, M, N, K, 0, nullptr, 0, nullptr, nullptr));
+    LXCHK(lx2v_gemm_bf16(a, K, nullptr, w, K, bias, c, N, M, N, K, 0, nullptr, 0, nullptr, nullptr));
     HIPCHK(hipDeviceSynchronize());
     std::vector<uint16_t> ha((size_t)K), hw((size_t)K);
     double maxerr = 0;

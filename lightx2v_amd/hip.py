@@ -26,7 +26,7 @@ _SIGNATURES = {
     "lx2v_rmsnorm_rope_bf16": [_P, _I64, _P, _I, _P, _I, _P, _I64, _I64, _I, _F, _P],
     "lx2v_gate_residual_bf16": [_P, _I64, _P, _I64, _P, _I64, _I, _P],
     "lx2v_gelu_tanh_bf16": [_P, _P, _I64, _P],
-    "lx2v_gemm_bf16": [_P, _I64, _I64, _I64, _P, _I64, _P, _P, _I64, _I64, _I64, _I64, _I, _P, _I64, _P, _P],
+    "lx2v_gemm_bf16": [_P, _I64, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _I64, _I, _P, _I64, _P, _P],
     "lx2v_attn_fwd_bf16": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I, _I, _F, _P, _P],
     "lx2v_ulysses_pack_qkv_bf16": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _I, _P],
     "lx2v_patchify_bf16": [_P, _P, _I64, _I, _I, _I, _I, _I, _P],
@@ -37,6 +37,8 @@ _SIGNATURES = {
     "lx2v_cfg_combine_f32": [_P, _P, _P, _F, _I64, _P],
     "lx2v_attn_fp8_workspace_bytes": [_I64, _I64, _I],
     "lx2v_attn_fwd_fp8": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I, _I, _F, _P, _I64, _P],
+    "lx2v_set_option": [ctypes.c_char_p, _I],
+    "lx2v_get_option": [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)],
     "lx2v_quant_fp8_rowwise": [_P, _I64, _P, _I64, _P, _I64, _I, _P],
     "lx2v_dequant_fp8_rowwise": [_P, _I64, _P, _P, _I64, _I64, _I, _P],
     "lx2v_gemm_fp8": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _P, _I64, _P, _P],
@@ -63,7 +65,7 @@ def load() -> ctypes.CDLL:
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_int64 if name == "lx2v_attn_fp8_workspace_bytes" else ctypes.c_int
+        fn.restype = ctypes.c_int64 if name in ("lx2v_attn_fp8_workspace_bytes",) else ctypes.c_int
     lib.lx2v_abi_version.restype = ctypes.c_int
     lib.lx2v_last_error.restype = ctypes.c_char_p
     _lib = lib
@@ -72,6 +74,14 @@ def load() -> ctypes.CDLL:
 
 class Lx2vError(RuntimeError):
     pass
+
+
+class KSeg(ctypes.Structure):
+    """`lx2v_kseg`: a GEMM A operand whose K columns are stored as segments.  Region 1: segments of
+    `seg` columns, `stride` elements apart; from K column `split` on (0 = one region): segments of
+    `seg2` columns, `stride2` apart, the first one `base2` elements from the tensor's start, rows
+    `lda2` elements apart."""
+    _fields_ = [("seg", _I64), ("stride", _I64), ("split", _I64), ("seg2", _I64), ("stride2", _I64), ("base2", _I64), ("lda2", _I64)]
 
 
 def _check(status: int, what: str):
@@ -97,6 +107,30 @@ def _need_bf16_cuda(name: str, t: torch.Tensor, inner_contig: bool = True):
         raise Lx2vError(f"{name}: innermost dimension must be contiguous")
 
 
+def _need_out(name: str, t: torch.Tensor, shape, like: torch.Tensor, dtype=torch.bfloat16):
+    """A caller-supplied output / residual slot: same device as the input, exact shape and dtype,
+    contiguous innermost dimension (rows may be strided: the slots are often views)."""
+    if not t.is_cuda or t.device != like.device:
+        raise Lx2vError(f"{name}: expected a tensor on {like.device}, got {t.device}")
+    if t.dtype != dtype:
+        raise Lx2vError(f"{name}: expected {dtype}, got {t.dtype}")
+    if tuple(t.shape) != tuple(shape):
+        raise Lx2vError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    if t.stride(-1) != 1:
+        raise Lx2vError(f"{name}: innermost dimension must be contiguous")
+
+
+def set_option(name: str, value: int):
+    """Kernel-selection switch (see include/lx2v_hip.h); every setting computes the same function."""
+    _check(load().lx2v_set_option(name.encode(), int(value)), "lx2v_set_option")
+
+
+def get_option(name: str) -> int:
+    v = ctypes.c_int(0)
+    _check(load().lx2v_get_option(name.encode(), ctypes.byref(v)), "lx2v_get_option")
+    return v.value
+
+
 def _vec_f32(name: str, t: Optional[torch.Tensor], n: int, like: torch.Tensor) -> Optional[torch.Tensor]:
     """scale/shift/gate/bias/norm-weight vectors: any float dtype / shape with n elements -> fp32 [n]."""
     if t is None:
@@ -117,6 +151,8 @@ def ln_modulate(x: torch.Tensor, ln_w=None, ln_b=None, scale=None, shift=None, e
     rows, dim = x.shape
     if out is None:
         out = torch.empty((rows, dim), dtype=x.dtype, device=x.device)
+    else:
+        _need_out("ln_modulate.out", out, (rows, dim), x)
     w = _vec_f32("ln_w", ln_w, dim, x)
     b = _vec_f32("ln_b", ln_b, dim, x)
     sc = _vec_f32("scale", scale, dim, x)
@@ -137,6 +173,8 @@ def rmsnorm_rope(x: torch.Tensor, weight=None, rope_cos_sin: Optional[torch.Tens
     rows, dim = x.shape
     if out is None:
         out = torch.empty((rows, dim), dtype=x.dtype, device=x.device)
+    else:
+        _need_out("rmsnorm_rope.out", out, (rows, dim), x)
     w = _vec_f32("rms weight", weight, head_dim if per_head else dim, x)
     do_norm = 2 if (do_norm and per_head) else int(bool(do_norm))
     if rope_cos_sin is not None:
@@ -165,28 +203,38 @@ def gelu_tanh(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tens
         raise Lx2vError("gelu_tanh: input must be contiguous")
     if out is None:
         out = torch.empty_like(x)
+    else:
+        _need_out("gelu.out", out, x.shape, x)
+        if not out.is_contiguous():
+            raise Lx2vError("gelu_tanh: out must be contiguous")
     st = load().lx2v_gelu_tanh_bf16(x.data_ptr(), out.data_ptr(), x.numel(), _stream())
     _check(st, "lx2v_gelu_tanh_bf16")
     return out
 
 
 def gemm(a: torch.Tensor, w_out_in: torch.Tensor, bias=None, epilogue: int = EPI_NONE, resid: Optional[torch.Tensor] = None,
-         gate=None, out: Optional[torch.Tensor] = None, a_kseg: int = 0, a_kseg_stride: int = 0, k_total: Optional[int] = None) -> torch.Tensor:
-    """C = epilogue(a @ w_out_in.T + bias).  a [M,K] bf16, w_out_in [N,K] bf16 (checkpoint layout)."""
+         gate=None, out: Optional[torch.Tensor] = None, kseg: Optional[KSeg] = None) -> torch.Tensor:
+    """C = epilogue(a @ w_out_in.T + bias).  a [M,K] bf16, w_out_in [N,K] bf16 (checkpoint layout).
+    With `kseg`, `a` is [M, seg] rows of the FIRST segment and the other segments are found through
+    the strides in `kseg` (the caller guarantees they lie inside one allocation)."""
     _need_bf16_cuda("gemm.a", a)
     _need_bf16_cuda("gemm.w", w_out_in)
     assert a.dim() == 2 and w_out_in.dim() == 2
     M = a.shape[0]
     N, K = w_out_in.shape
-    if a_kseg == 0 and a.shape[1] != K:
+    if kseg is None and a.shape[1] != K:
         raise Lx2vError(f"gemm: inner dimensions differ: a {tuple(a.shape)} vs w {tuple(w_out_in.shape)}")
     if out is None:
         out = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    else:
+        _need_out("gemm.out", out, (M, N), a)
     b = _vec_f32("bias", bias, N, a)
     g = _vec_f32("gate", gate, N, a)
     if resid is not None:
-        _need_bf16_cuda("gemm.resid", resid)
-    st = load().lx2v_gemm_bf16(a.data_ptr(), a.stride(0), a_kseg, a_kseg_stride, w_out_in.data_ptr(), w_out_in.stride(0), _ptr(b),
+        _need_out("gemm.resid", resid, (M, N), a)
+    elif epilogue == EPI_RESIDUAL:
+        raise Lx2vError("gemm: the residual epilogue needs `resid`")
+    st = load().lx2v_gemm_bf16(a.data_ptr(), a.stride(0), None if kseg is None else ctypes.byref(kseg), w_out_in.data_ptr(), w_out_in.stride(0), _ptr(b),
                                out.data_ptr(), out.stride(0), M, N, K, epilogue, _ptr(resid), 0 if resid is None else resid.stride(0),
                                _ptr(g), _stream())
     _check(st, "lx2v_gemm_bf16")
@@ -208,6 +256,8 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional[
         scale = d ** -0.5
     if out is None:
         out = torch.empty((sq, H * d), dtype=q.dtype, device=q.device)
+    else:
+        _need_out("attn.out", out, (sq, H * d), q)
     if rope_cos_sin is not None:
         if rope_cos_sin.dtype != torch.float32 or not rope_cos_sin.is_contiguous() or tuple(rope_cos_sin.shape) != (sq, d):
             raise Lx2vError(f"attn: rope table must be contiguous fp32 [{sq}, {d}]")
@@ -233,6 +283,8 @@ def attn_fwd_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optio
         scale = d ** -0.5
     if out is None:
         out = torch.empty((sq, H * d), dtype=q.dtype, device=q.device)
+    else:
+        _need_out("attn_fp8.out", out, (sq, H * d), q)
     need = attn_fp8_workspace_bytes(sq, skv, H)
     if workspace is None:
         workspace = torch.empty(need, dtype=torch.uint8, device=q.device)
@@ -256,8 +308,17 @@ def ulysses_pack_qkv(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, world: i
     for n, t in (("q", q), ("k", k), ("v", v)):
         _need_bf16_cuda("pack." + n, t)
     rows, dim = q.shape
+    if dim % world != 0:
+        raise Lx2vError(f"ulysses_pack_qkv: dim={dim} not divisible by world={world}")
+    for n, t in (("k", k), ("v", v)):
+        if tuple(t.shape) != (rows, dim):
+            raise Lx2vError(f"ulysses_pack_qkv: {n} {tuple(t.shape)} differs from q {(rows, dim)}")
     if out is None:
         out = torch.empty((world, rows, 3, dim // world), dtype=q.dtype, device=q.device)
+    else:
+        _need_out("ulysses_pack_qkv.out", out, (world, rows, 3, dim // world), q)
+        if not out.is_contiguous():
+            raise Lx2vError("ulysses_pack_qkv: out must be contiguous")
     st = load().lx2v_ulysses_pack_qkv_bf16(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
                                            out.data_ptr(), rows, dim, world, _stream())
     _check(st, "lx2v_ulysses_pack_qkv_bf16")
@@ -356,9 +417,7 @@ def dequant_fp8_rowwise(q: torch.Tensor, scale: torch.Tensor, out: Optional[torc
     scale = _vec_f32("dequant_fp8.scale", scale, rows, q)
     if out is None:
         out = torch.empty((rows, dim), dtype=torch.bfloat16, device=q.device)
-    _need_bf16_cuda("dequant_fp8.out", out)
-    if tuple(out.shape) != (rows, dim) or out.stride(1) != 1:
-        raise Lx2vError(f"dequant_fp8: out must be [{rows}, {dim}] with a contiguous inner dimension")
+    _need_out("dequant_fp8.out", out, (rows, dim), q)
     _check(load().lx2v_dequant_fp8_rowwise(q.data_ptr(), q.stride(0), scale.data_ptr(), out.data_ptr(), out.stride(0), rows, dim, _stream()), "lx2v_dequant_fp8_rowwise")
     return out
 
@@ -379,8 +438,12 @@ def gemm_fp8(a8: torch.Tensor, a_scale: torch.Tensor, w8: torch.Tensor, w_scale:
     gate = _vec_f32("gemm_fp8.gate", gate, N, a8)
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=a8.device)
-    if epilogue == EPI_RESIDUAL:
-        _need_bf16_cuda("gemm_fp8.resid", resid)
+    else:
+        _need_out("gemm_fp8.out", out, (M, N), a8)
+    if resid is not None:
+        _need_out("gemm_fp8.resid", resid, (M, N), a8)
+    elif epilogue == EPI_RESIDUAL:
+        raise Lx2vError("gemm_fp8: the residual epilogue needs `resid`")
     st = load().lx2v_gemm_fp8(a8.data_ptr(), a8.stride(0), a_scale.data_ptr(), w8.data_ptr(), w8.stride(0), w_scale.data_ptr(), _ptr(bias),
                               out.data_ptr(), out.stride(0), M, N, K, epilogue, _ptr(resid), 0 if resid is None else resid.stride(0), _ptr(gate), _stream())
     _check(st, "lx2v_gemm_fp8")

@@ -78,17 +78,13 @@ class _Branch(WeightModule):
         self.add_module(f"{br}_norm2", ln())
         self.add_module(f"{br}_mlp_fc1", mm(p + "mlp.fc1.weight", p + "mlp.fc1.bias", *extra))
         self.add_module(f"{br}_mlp_fc2", mm(p + "mlp.fc2.weight", p + "mlp.fc2.bias", *extra))
-        self._qkv = None
 
     def part(self, name):
         return getattr(self, f"{self.br}_{name}")
 
     def fused_qkv(self):
-        """One Linear with the [3D, D] q|k|v weight; built once, the three plugins then alias it."""
-        if self._qkv is None:
-            q = self.part("attn_q")
-            self._qkv = type(q).fused([q, self.part("attn_k"), self.part("attn_v")])
-        return self._qkv
+        """One Linear with the [3D, D] q|k|v weight; the three plugins then alias it."""
+        return self.fused("qkv", [self.part("attn_q"), self.part("attn_k"), self.part("attn_v")])
 
 
 class MMDoubleStreamBlockImgBranch(_Branch):

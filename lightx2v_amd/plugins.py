@@ -46,6 +46,28 @@ def _device_ready(t: Optional[torch.Tensor], dtype) -> Optional[torch.Tensor]:
     return t.to(dtype=dtype).contiguous()
 
 
+def _cat_bias(mods) -> Optional[torch.Tensor]:
+    """Concatenated fp32 bias of Linear plugins that are fused row-wise; a member without a bias
+    contributes zeros, and no member having one gives None."""
+    if all(m.bias is None for m in mods):
+        return None
+    like = next(m.bias for m in mods if m.bias is not None)
+    return torch.cat([m.bias if m.bias is not None else torch.zeros(m.weight_nk.shape[0], dtype=like.dtype, device=like.device) for m in mods]).contiguous()
+
+
+def _one_sequence(who: str, name: str, cu, max_seqlen, rows: int):
+    """The kernels attend over every row they are given, so a varlen description that says
+    anything else (more than one sequence, or fewer rows than the tensor holds: the reference's
+    flash_attn_varlen_func would stop at cu_seqlens[-1]) is refused instead of mis-computed."""
+    if cu is not None:
+        if cu.numel() != 2:
+            raise NotImplementedError(f"{who}: {name} must describe one sequence, got {cu.numel() - 1}")
+        if not cu.is_cuda and (int(cu[0]) != 0 or int(cu[-1]) != rows):  # a host tensor costs no device sync to read
+            raise ValueError(f"{who}: {name}={cu.tolist()} does not cover the {rows} rows of the tensor; slice the tensor to the sequence")
+    if max_seqlen is not None and int(max_seqlen) != rows:
+        raise ValueError(f"{who}: max_seqlen={int(max_seqlen)} differs from the tensor's {rows} rows; slice the tensor to the sequence")
+
+
 # ----------------------------------------------------------------------------------- attention
 class _AttnBase:
     """No-op weight plumbing every attention plugin inherits (attn/template.py:4-32)."""
@@ -91,9 +113,8 @@ class HipFlashAttnWeight(_AttnBase):
             if q.shape[0] != 1:
                 raise NotImplementedError("hip_flash_attn: batch > 1 is not part of the Wan block path")
             q, k, v = q[0], k[0], v[0]
-        for name, cu, s in (("cu_seqlens_q", cu_seqlens_q, q.shape[0]), ("cu_seqlens_kv", cu_seqlens_kv, k.shape[0])):
-            if cu is not None and cu.numel() != 2:
-                raise NotImplementedError(f"hip_flash_attn: {name} must describe one sequence, got {cu.numel() - 1}")
+        _one_sequence("hip_flash_attn", "cu_seqlens_q", cu_seqlens_q, max_seqlen_q, q.shape[0])
+        _one_sequence("hip_flash_attn", "cu_seqlens_kv", cu_seqlens_kv, max_seqlen_kv, k.shape[0])
         rope, self.rope_cos_sin = self.rope_cos_sin, None
         return hip.attn_fwd(q, k, v, rope_cos_sin=rope)
 
@@ -118,9 +139,8 @@ class HipFp8AttnWeight(_AttnBase):
             if q.shape[0] != 1:
                 raise NotImplementedError("hip_fp8_attn: batch > 1 is not part of the block path")
             q, k, v = q[0], k[0], v[0]
-        for name, cu in (("cu_seqlens_q", cu_seqlens_q), ("cu_seqlens_kv", cu_seqlens_kv)):
-            if cu is not None and cu.numel() != 2:
-                raise NotImplementedError(f"hip_fp8_attn: {name} must describe one sequence, got {cu.numel() - 1}")
+        _one_sequence("hip_fp8_attn", "cu_seqlens_q", cu_seqlens_q, max_seqlen_q, q.shape[0])
+        _one_sequence("hip_fp8_attn", "cu_seqlens_kv", cu_seqlens_kv, max_seqlen_kv, k.shape[0])
         need = hip.attn_fp8_workspace_bytes(q.shape[0], k.shape[0], q.shape[1])
         if self._workspace is None or self._workspace.numel() < need or self._workspace.device != q.device:
             self._workspace = torch.empty(need, dtype=torch.uint8, device=q.device)
@@ -166,12 +186,12 @@ class HipMMWeight:
         their separate copies are released."""
         out = cls(None, None)
         w = torch.cat([m.weight_nk for m in mods], dim=0).contiguous()
-        b = torch.cat([m.bias for m in mods], dim=0).contiguous()
+        b = _cat_bias(mods)
         out.adopt(w, b)
         o = 0
         for m in mods:
             n = m.weight_nk.shape[0]
-            m.adopt(w[o:o + n], b[o:o + n])
+            m.adopt(w[o:o + n], None if (b is None or m.bias is None) else b[o:o + n])
             o += n
         return out
 
@@ -230,10 +250,10 @@ class HipMMWeight:
     def apply_gelu(self, input_tensor):
         return hip.gemm(input_tensor, self.weight_nk, self.bias, epilogue=hip.EPI_GELU_TANH)
 
-    def apply_residual_(self, input_tensor, resid, gate=None, a_kseg=0, a_kseg_stride=0):
-        """resid <- resid + (x W^T + b) * gate, in place; returns resid."""
-        return hip.gemm(input_tensor, self.weight_nk, self.bias, epilogue=hip.EPI_RESIDUAL, resid=resid, gate=gate, out=resid,
-                        a_kseg=a_kseg, a_kseg_stride=a_kseg_stride)
+    def apply_residual_(self, input_tensor, resid, gate=None, kseg=None):
+        """resid <- resid + (x W^T + b) * gate, in place; returns resid.  `kseg` (hip.KSeg): the
+        input's K columns are stored as segments, `input_tensor` being the rows of the first one."""
+        return hip.gemm(input_tensor, self.weight_nk, self.bias, epilogue=hip.EPI_RESIDUAL, resid=resid, gate=gate, out=resid, kseg=kseg)
 
 
 @MM_WEIGHT_REGISTER("hip-fp8")
@@ -294,13 +314,13 @@ class HipFp8MMWeight(HipMMWeight):
     def fused(cls, mods):
         out = cls(None, None)
         w = torch.cat([m.weight_nk for m in mods], dim=0).contiguous()
-        b = torch.cat([m.bias for m in mods], dim=0).contiguous()
+        b = _cat_bias(mods)
         sc = torch.cat([m.weight_scale for m in mods], dim=0).contiguous()
         out.adopt(w, b, sc)
         o = 0
         for m in mods:
             n = m.weight_nk.shape[0]
-            m.adopt(w[o:o + n], b[o:o + n], sc[o:o + n])
+            m.adopt(w[o:o + n], None if (b is None or m.bias is None) else b[o:o + n], sc[o:o + n])
             o += n
         return out
 
@@ -315,8 +335,8 @@ class HipFp8MMWeight(HipMMWeight):
     def apply_gelu(self, input_tensor):
         return self._run(input_tensor, hip.EPI_GELU_TANH)
 
-    def apply_residual_(self, input_tensor, resid, gate=None, a_kseg=0, a_kseg_stride=0):
-        if a_kseg != 0:
+    def apply_residual_(self, input_tensor, resid, gate=None, kseg=None):
+        if kseg is not None:
             raise NotImplementedError("hip-fp8: K-segmented operands are built for the bf16 scheme only")
         return self._run(input_tensor, hip.EPI_RESIDUAL, resid=resid, gate=gate)
 

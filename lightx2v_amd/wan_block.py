@@ -69,14 +69,11 @@ class WanSelfAttention(WeightModule):
         self.add_module("self_attn_1", ATTN_WEIGHT_REGISTER[config["self_attn_1_type"]]())
         if config["seq_parallel"]:
             self.add_module("self_attn_1_parallel", ATTN_WEIGHT_REGISTER[config.get("parallel", {}).get("seq_p_attn_type", "hip_ulysses")]())
-        self._qkv = None
 
     def fused_qkv(self):
-        """One Linear with the [3D, D] q|k|v weight (one GEMM instead of three).  Built once; the
-        q/k/v plugins are then re-pointed at slices of it so the separate copies are released."""
-        if self._qkv is None:
-            self._qkv = type(self.self_attn_q).fused([self.self_attn_q, self.self_attn_k, self.self_attn_v])
-        return self._qkv
+        """One Linear with the [3D, D] q|k|v weight (one GEMM instead of three); the q/k/v plugins
+        are re-pointed at slices of it so the separate copies are released."""
+        return self.fused("qkv", [self.self_attn_q, self.self_attn_k, self.self_attn_v])
 
 
 class WanCrossAttention(WeightModule):
@@ -97,12 +94,9 @@ class WanCrossAttention(WeightModule):
             self.add_module("cross_attn_v_img", mm(f"{p}.cross_attn.v_img.weight", f"{p}.cross_attn.v_img.bias", *extra))
             self.add_module("cross_attn_norm_k_img", rms(f"{p}.cross_attn.norm_k_img.weight", *extra))
             self.add_module("cross_attn_2", ATTN_WEIGHT_REGISTER[config["cross_attn_2_type"]]())
-        self._kv = None
 
     def fused_kv(self):
-        if self._kv is None:
-            self._kv = type(self.cross_attn_k).fused([self.cross_attn_k, self.cross_attn_v])
-        return self._kv
+        return self.fused("kv", [self.cross_attn_k, self.cross_attn_v])
 
 
 class WanFFN(WeightModule):
@@ -266,8 +260,8 @@ class WanTransformerInfer:
             if self.fused_block and hasattr(par, "apply_segmented") and phase.self_attn_o.supports_kseg:
                 # the all-to-all result stays in its [source rank][S/N][H/N*d] receive layout; the
                 # output projection reads it as a K-segmented A operand (no gather copy)
-                recv, kseg, kseg_stride = par.apply_segmented(q, k, v, attention_module=phase.self_attn_1, seq_p_group=self.seq_p_group, use_fp8_comm=self.seq_p_fp8_comm)
-                phase.self_attn_o.apply_residual_(recv, x, gate_msa, a_kseg=kseg, a_kseg_stride=kseg_stride)
+                op = par.apply_segmented(q, k, v, attention_module=phase.self_attn_1, seq_p_group=self.seq_p_group, use_fp8_comm=self.seq_p_fp8_comm)
+                phase.self_attn_o.apply_residual_(op.first, x, gate_msa, kseg=op.kseg)
                 return None
             attn_out = par.apply(q=q, k=k, v=v, img_qkv_len=S, cu_seqlens_qkv=cu, attention_module=phase.self_attn_1,
                                  seq_p_group=self.seq_p_group, use_fp8_comm=self.seq_p_fp8_comm, model_cls=self.config["model_cls"])

@@ -20,7 +20,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import hip
+from . import comm, hip
 from .registry_factory import CONV3D_WEIGHT_REGISTER, MM_WEIGHT_REGISTER
 from .rope_table import build_rope_table, shard_rope_table
 from .wan_block import WanPreInferModuleOutput, WanTransformerInfer, WanTransformerWeights, with_defaults
@@ -372,7 +372,7 @@ class WanModel:
                 assert dist.get_world_size(self.cfg_p_group) == 2, "cfg_p_world_size must be equal to 2"
                 mine = self._infer_cond_uncond(inputs, infer_condition=dist.get_rank(self.cfg_p_group) == 0)
                 parts = [torch.empty_like(mine) for _ in range(2)]
-                dist.all_gather(parts, mine, group=self.cfg_p_group)
+                comm.transport().all_gather(parts, mine.contiguous(), group=self.cfg_p_group)
                 cond, uncond = parts
             else:
                 cond = self._infer_cond_uncond(inputs, infer_condition=True)
@@ -405,7 +405,7 @@ class WanModel:
     def _seq_parallel_post_process(self, x):
         world = dist.get_world_size(self.seq_p_group)
         gathered = [torch.empty_like(x) for _ in range(world)]
-        dist.all_gather(gathered, x.contiguous(), group=self.seq_p_group)
+        comm.transport().all_gather(gathered, x.contiguous(), group=self.seq_p_group)
         return torch.cat(gathered, dim=0)
 
 

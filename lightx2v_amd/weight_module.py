@@ -15,6 +15,7 @@ class WeightModule:
     def __init__(self):
         self._modules: Dict[str, Any] = {}
         self._parameters: Dict[str, Any] = {}
+        self._fused: Dict[str, Any] = {}
 
     # ---- tree construction --------------------------------------------------------------------
     def add_module(self, name: str, module: Any):
@@ -38,14 +39,32 @@ class WeightModule:
             if fn is not None:
                 fn(*args, **kwargs)
 
+    # ---- fused views ----------------------------------------------------------------------------
+    def fused(self, key: str, members):
+        """One Linear plugin over the row-wise concatenation of `members`' weights (q|k|v, k|v): one
+        GEMM instead of several.  Built on first use; the members are then re-pointed at slices of
+        the fused storage, so there is one copy.  The cached plugin is dropped whenever the
+        members' weights can change (`load`, `load_state_dict`, `clear`, device moves) and is
+        rebuilt if a member no longer lives in its storage."""
+        cached = self._fused.get(key)
+        if cached is not None:
+            base = cached.weight_nk.untyped_storage().data_ptr()
+            if all(m.weight_nk is not None and m.weight_nk.untyped_storage().data_ptr() == base for m in members):
+                return cached
+        built = type(members[0]).fused(members)
+        self._fused[key] = built
+        return built
+
     # ---- weights ------------------------------------------------------------------------------
     def load(self, weight_dict: Dict[str, Any]):
+        self._fused.clear()
         self._fanout("load", weight_dict)
 
     def load_from_disk(self):
         self._fanout("load_from_disk")
 
     def clear(self):
+        self._fused.clear()
         self._fanout("clear")
 
     def calculate_size(self) -> int:
@@ -71,6 +90,7 @@ class WeightModule:
     def load_state_dict(self, destination: Optional[dict], block_index: int, adapter_block_index: Optional[int] = None) -> dict:
         if destination is None:
             destination = {}
+        self._fused.clear()
         for child in list(self._parameters.values()) + list(self._modules.values()):
             if child is not None:
                 child.load_state_dict(destination, block_index, adapter_block_index)
@@ -90,6 +110,7 @@ class WeightModule:
 
     # ---- device moves -------------------------------------------------------------------------
     def _move(self, method: str, non_blocking: bool):
+        self._fused.clear()  # the members are moved one by one and stop aliasing the fused storage
         for child in self._children():
             if isinstance(child, WeightModule):
                 child._move(method, non_blocking)

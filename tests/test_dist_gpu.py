@@ -1,7 +1,7 @@
-"""The sequence-parallel block on the real HIP kernels: 2 ranks share the one GPU and exchange
-through gloo (which carries CUDA tensors via the host), so the pack kernel, the strided attention
-reads, the return all-to-all and the K-segmented output projection are exercised end to end and
-compared with the unsharded block on the same inputs."""
+"""The sequence-parallel and CFG-parallel paths on the real HIP kernels: 2 or 4 ranks share the one
+GPU and exchange through gloo on host copies, so the pack kernel, the strided attention reads, the
+return all-to-all, the K-segmented output projection and the model-level gathers are exercised end
+to end and compared with the unsharded run on the same inputs."""
 import os
 import socket
 
@@ -21,38 +21,60 @@ def _free_port():
     return port
 
 
-def _spawn(fn, args, nprocs, attempt_s=120, attempts=2):
-    """mp.spawn with a deadline per attempt.  gloo moving CUDA tensors of processes that share one
-    GPU stalls once in a while (a transport artefact of this one-GPU stand-in, not of the code under
-    test); a stalled attempt is ended by killing exactly the processes it started, and run again
-    on a fresh port.  `args` is called with the port to build the worker arguments."""
+def _spawn(fn, args, nprocs, deadline_s=150):
+    """mp.spawn under a deadline, once: every worker arms a stack dump shortly before it, so a
+    stall names the collective each rank is parked in instead of being retried."""
     import time
-    for k in range(attempts):
-        ctx = mp.spawn(fn, args=args(_free_port()), nprocs=nprocs, join=False)
-        t_end = time.time() + attempt_s
-        while time.time() < t_end:
-            if ctx.join(timeout=1.0):   # raises if a worker failed
-                return
-        for pr in ctx.processes:
-            if pr.is_alive():
-                pr.kill()
-        for pr in ctx.processes:
-            pr.join(10)
-    pytest.fail(f"{fn.__name__}: {attempts} attempts of {attempt_s} s each stalled")
+    ctx = mp.spawn(fn, args=args(_free_port()), nprocs=nprocs, join=False)
+    t_end = time.time() + deadline_s
+    while time.time() < t_end:
+        if ctx.join(timeout=1.0):   # raises if a worker failed
+            return
+    for pr in ctx.processes:
+        if pr.is_alive():
+            pr.kill()
+    for pr in ctx.processes:
+        pr.join(10)
+    pytest.fail(f"{fn.__name__}: stalled for {deadline_s} s (stack dumps of the ranks are in the captured stderr)")
 
 
-def _worker(rank, world, port, out_dir, fused, fp8_comm=False):
+def _init(rank, world, port):
+    """Process group + transport of a rank that shares GPU 0 with the others.  RCCL refuses two ranks
+    on one device and gloo's own CUDA path stalls there (tools/probe_gloo_shared_gpu.py), so gloo is
+    handed host copies; the product's issue order and asynchrony are unchanged."""
+    import faulthandler
+
+    faulthandler.dump_traceback_later(130, exit=True)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lightx2v_amd import comm
+
+    comm.set_transport(comm.HostStagedTransport())
+    torch.cuda.set_device(0)
+    return torch.device("cuda:0")
+
+
+def _finish():
+    import faulthandler
+
+    torch.cuda.synchronize()
+    dist.barrier()
+    faulthandler.cancel_dump_traceback_later()
+    dist.destroy_process_group()
+
+
+H10_CASE = {"grid": (3, 5, 7), "dim": 1280, "heads": 10, "ffn": 2560, "text_len": 77, "seed": 11}  # 5 heads per rank of 2: chunks of 3 + 2
+
+
+def _worker(rank, world, port, out_dir, fused, fp8_comm=False, case=None):
+    dev = _init(rank, world, port)
     import lightx2v_amd as L
     from lightx2v_amd import ulysses
     from oracle import wan_block_ref as R
     from tests.util import case_inputs, load_golden
 
-    dev = torch.device("cuda:0")
-    torch.cuda.set_device(0)
-    rec = load_golden("small_d512_g3x5x7")  # S = 105 (odd: exercises the zero padding), H = 4
+    rec = load_golden("small_d512_g3x5x7") if case is None else case  # S = 105 (odd: exercises the zero padding), H = 4
     c = case_inputs(rec)
     _, seq_idx, seq_group, _ = ulysses.make_groups(1, world)
     cfg = {"num_layers": 1, "num_heads": c["heads"], "dim": c["dim"], "task": "t2v", "seq_parallel": True, "seq_p_group": seq_group,
@@ -74,8 +96,7 @@ def _worker(rank, world, port, out_dir, fused, fp8_comm=False):
     out = inf.infer_block(W.blocks[0], pre.x, pre)
     torch.cuda.synchronize()
     torch.save(out.float().cpu(), os.path.join(out_dir, f"o{rank}_{int(fused)}{'_fp8' if fp8_comm else ''}.pt"))
-    dist.barrier()
-    dist.destroy_process_group()
+    _finish()
 
 
 @pytest.mark.parametrize("fused", [True, False])
@@ -92,6 +113,26 @@ def test_sequence_parallel_block_two_ranks_one_gpu(cuda, tmp_path, fused):
     # padded token has q = k = 0 after RoPE but still takes part in the softmax as a key
     # (lightx2v/models/schedulers/wan/scheduler.py:106-113); real tokens therefore differ from the
     # un-padded run by that extra key, exactly as in the reference.
+    S, D = c["S"], c["dim"]
+    xp = torch.zeros(S + 1, D); xp[:S] = c["x"]
+    cs = torch.cat([c["cos_sin"], torch.zeros(1, 1, c["cos_sin"].shape[-1], dtype=c["cos_sin"].dtype)])
+    ref = R.block_forward(xp, c["embed0"], c["context"], c["w"], cs, c["heads"])[:S]
+    assert cos(got, ref) >= 0.9999
+    assert cos(got - c["x"], ref - c["x"]) >= 0.995
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_sequence_parallel_block_uneven_head_chunks(cuda, tmp_path, fused):
+    """10 heads on 2 ranks = 5 heads per rank, attended as chunks of 3 and 2 heads (the shape of
+    Wan-14B at seq_p = 8): two all-to-alls of different widths and, in the fused block, an output
+    projection that reads its operand from segments of two widths."""
+    from oracle import wan_block_ref as R
+    from tests.util import case_inputs, cos
+
+    world = 2
+    _spawn(_worker, lambda port: (world, port, str(tmp_path), fused, False, H10_CASE), world)
+    c = case_inputs(H10_CASE)
+    got = torch.cat([torch.load(os.path.join(str(tmp_path), f"o{r}_{int(fused)}.pt")) for r in range(world)])[:c["S"]]
     S, D = c["S"], c["dim"]
     xp = torch.zeros(S + 1, D); xp[:S] = c["x"]
     cs = torch.cat([c["cos_sin"], torch.zeros(1, 1, c["cos_sin"].shape[-1], dtype=c["cos_sin"].dtype)])
@@ -124,16 +165,12 @@ def test_sequence_parallel_block_fp8_payload(cuda, tmp_path, fused):
 
 
 def _hy_worker(rank, world, port, out_dir):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = _init(rank, world, port)
     import lightx2v_amd as L
     from lightx2v_amd import ulysses
     from tests.test_hy_oracle import hy_case_inputs
     from tests.util import load_golden
 
-    dev = torch.device("cuda:0")
-    torch.cuda.set_device(0)
     c = hy_case_inputs(load_golden("hy_tiny_d256"))  # 48 image tokens + 19 text tokens, H = 2
     _, seq_idx, seq_group, _ = ulysses.make_groups(1, world)
     cfg = {"mm_double_blocks_depth": c["depth"], "heads_num": c["heads"], "hidden_size": c["dim"], "seq_parallel": True, "seq_p_group": seq_group,
@@ -153,8 +190,7 @@ def _hy_worker(rank, world, port, out_dir):
     out = inf.infer(W, io)  # both blocks + final layer on this rank's image rows
     torch.cuda.synchronize()
     torch.save({"final": out.float().cpu(), "txt": io.txt.float().cpu()}, os.path.join(out_dir, f"hy{rank}.pt"))
-    dist.barrier()
-    dist.destroy_process_group()
+    _finish()
 
 
 def test_hunyuan_double_blocks_sequence_parallel_two_ranks_one_gpu(cuda, tmp_path):
@@ -169,3 +205,56 @@ def test_hunyuan_double_blocks_sequence_parallel_two_ranks_one_gpu(cuda, tmp_pat
     got = torch.cat([r["final"][0] for r in res])
     assert cos(got, torch.from_numpy(rec["final_out"])) >= 0.9995
     assert cos(res[0]["txt"], res[1]["txt"]) >= 0.99999
+
+
+# ---- WanModel.infer with cfg_parallel / seq_parallel (lightx2v/models/networks/wan/model.py:412-433,468-499) ----
+def _model_worker(rank, world, port, out_dir, cfg_p, seq_p, chunks):
+    os.environ["LX2V_ULYSSES_CHUNKS"] = str(chunks)
+    dev = _init(rank, world, port)
+    import lightx2v_amd as L
+    from lightx2v_amd import ulysses
+    from tests.test_step_oracle import step_case
+
+    rec, meta, model = step_case("step_small_d512")   # 105 tokens: odd, so every seq_p > 1 pads
+    cfg_idx, seq_idx, seq_group, cfg_group = ulysses.make_groups(cfg_p, seq_p)
+    cfg = {"dim": meta["dim"], "num_heads": meta["heads"], "num_layers": meta["layers"], "ffn_dim": meta["ffn"], "in_dim": 16, "out_dim": 16,
+           "freq_dim": 256, "task": "t2v", "infer_steps": meta["steps"], "sample_shift": meta["shift"], "sample_guide_scale": meta["guide"],
+           "enable_cfg": True, "run_device": "cuda", "keep_latents_dtype_in_scheduler": True,
+           "cfg_parallel": cfg_p > 1, "cfg_p_group": cfg_group, "seq_parallel": seq_p > 1, "seq_p_group": seq_group,
+           "parallel": {"seq_p_size": seq_p, "cfg_p_size": cfg_p, "seq_p_attn_type": "hip_ulysses"}}
+    m = L.WanModel(cfg, weight_dict=dict(model))
+    m.to_cuda()
+    sch = L.WanScheduler(cfg)
+    m.set_scheduler(sch)
+    sch.prepare(meta["seed"], meta["latent_shape"], latents=torch.from_numpy(rec["latents0"]))
+    inputs = {"text_encoder_output": {k: torch.from_numpy(rec[k]).to(dev) for k in ("context", "context_null")}}
+    preds = []
+    for i in range(2):   # two steps: the second runs on latents the first produced
+        sch.step_pre(i)
+        m.infer(inputs)
+        preds.append(sch.noise_pred.float().cpu())
+        sch.step_post()
+    torch.save({"preds": preds, "latents": sch.latents.float().cpu()}, os.path.join(out_dir, f"m{rank}.pt"))
+    _finish()
+
+
+@pytest.mark.parametrize("cfg_p,seq_p,chunks", [(2, 1, 2), (1, 2, 2), (2, 2, 2), (2, 2, 1)])
+def test_model_infer_with_cfg_and_sequence_parallel_groups(cuda, tmp_path, cfg_p, seq_p, chunks):
+    """`WanModel.infer` on a (cfg_p, seq_p) grid of ranks: the CFG all_gather, the pad / chunk of the
+    tokens, Ulysses inside every block and the final all_gather.  Every rank must end with the same
+    noise prediction, equal to the reference's golden trajectory within the step tolerance (with
+    seq_p > 1 the one padded token takes part as a key with q = k = 0, as in the reference)."""
+    import numpy as np
+    from tests.test_step_oracle import step_case
+    from tests.util import cos
+
+    world = cfg_p * seq_p
+    _spawn(_model_worker, lambda port: (world, port, str(tmp_path), cfg_p, seq_p, chunks), world)
+    rec, meta, _ = step_case("step_small_d512")
+    res = [torch.load(os.path.join(str(tmp_path), f"m{r}.pt")) for r in range(world)]
+    for i in range(2):
+        gold = torch.from_numpy(np.asarray(rec[f"noise_pred_{i}"]))
+        for r in range(world):
+            assert cos(res[r]["preds"][i], gold) >= 0.999, (i, r, cos(res[r]["preds"][i], gold))
+            assert torch.equal(res[r]["preds"][i], res[0]["preds"][i]), (i, r)   # all ranks hold the combined prediction
+    assert cos(res[0]["latents"], torch.from_numpy(np.asarray(rec["latents_2"]))) >= 0.9995

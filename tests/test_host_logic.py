@@ -59,7 +59,7 @@ def test_c_abi_exports_every_declared_symbol():
     lib = ctypes.CDLL(hip.lib_path())
     for name in declared:
         assert hasattr(lib, name), name
-    assert hip.load().lx2v_abi_version() == 1
+    assert hip.load().lx2v_abi_version() == 2
 
 
 def test_ops_refuse_cpu_tensors_loudly():
@@ -75,11 +75,13 @@ def test_ops_refuse_cpu_tensors_loudly():
 def test_c_abi_argument_validation_without_launching():
     lib = hip.load()
     # null pointers / bad shapes are rejected before any HIP call
-    assert lib.lx2v_gemm_bf16(None, 64, 0, 0, None, 64, None, None, 64, 8, 8, 64, 0, None, 0, None, None) == -1
+    assert lib.lx2v_gemm_bf16(None, 64, None, None, 64, None, None, 64, 8, 8, 64, 0, None, 0, None, None) == -1
     assert b"null" in lib.lx2v_last_error()
     buf = ctypes.create_string_buffer(4096 + 16)
     p = (ctypes.addressof(buf) + 15) & ~15
-    assert lib.lx2v_gemm_bf16(p, 64, 0, 0, p, 64, None, p, 64, 8, 8, 63, 0, None, 0, None, None) == -2   # K % 64
+    assert lib.lx2v_gemm_bf16(p, 64, None, p, 64, None, p, 64, 8, 8, 63, 0, None, 0, None, None) == -2   # K % 64
+    bad = hip.KSeg(seg=64, stride=64, split=32, seg2=64, stride2=64, base2=0, lda2=64)
+    assert lib.lx2v_gemm_bf16(p, 64, ctypes.byref(bad), p, 64, None, p, 64, 8, 8, 128, 0, None, 0, None, None) == -1  # region 1 not a whole number of segments
     assert lib.lx2v_attn_fwd_bf16(p, 128, p, 128, p, 128, p, 128, 8, 8, 1, 64, 0.1, None, None) == -2      # head_dim != 128
     assert lib.lx2v_ln_modulate_bf16(p, 64, p, None, None, None, p, 64, 4, 64, 1e-6, None) == -1          # ln_w without ln_b
     assert lib.lx2v_ln_modulate_bf16(p + 2, 64, None, None, None, None, p, 64, 4, 64, 1e-6, None) == -1   # misaligned
@@ -160,3 +162,62 @@ def test_pre_process_chunk_order():
     assert len(parts) == 6
     for a, b in zip(parts, ref):
         assert torch.equal(a, b.reshape(-1))
+
+
+def test_fused_qkv_follows_reloads_and_moves():
+    """The fused q|k|v plugin is a cache of the members' weights: a second load() must replace it,
+    and a member without a bias must not break the fusion."""
+    cfg = _cfg(num_layers=1)
+    W = L.WanTransformerWeights(cfg)
+    w1 = R.make_block_weights(256, 512, seed=7)
+    w1.update(R.make_head_weights(256, 64, seed=7))
+    W.load(dict(w1))
+    sa, ca, _ = W.blocks[0].compute_phases
+    f1 = sa.fused_qkv()
+    assert sa.fused_qkv() is f1  # cached while the members alias it
+    kv1 = ca.fused_kv()
+    w2 = R.make_block_weights(256, 512, seed=8)
+    w2.update(R.make_head_weights(256, 64, seed=8))
+    W.load(dict(w2))
+    f2 = sa.fused_qkv()
+    assert f2 is not f1 and ca.fused_kv() is not kv1
+    assert torch.equal(f2.weight_nk[256:512].float(), w2["blocks.0.self_attn.k.weight"].to(torch.bfloat16).float())
+    assert torch.equal(f2.bias[:256], w2["blocks.0.self_attn.q.bias"].float())
+    # a member swapped by hand (e.g. a LoRA merge that re-assigns weight_nk) is noticed too
+    sa.self_attn_v.weight_nk = sa.self_attn_v.weight_nk.clone()
+    assert sa.fused_qkv() is not f2
+    # bias-less members: zeros stand in, all-None stays None
+    sa.self_attn_k.bias = None
+    f3 = sa.fused("qkv_nobias_k", [sa.self_attn_q, sa.self_attn_k, sa.self_attn_v])
+    assert torch.count_nonzero(f3.bias[256:512]) == 0 and sa.self_attn_k.bias is None and sa.self_attn_q.bias is not None
+    for m in (sa.self_attn_q, sa.self_attn_k, sa.self_attn_v):
+        m.bias = None
+    assert sa.fused("qkv_nobias", [sa.self_attn_q, sa.self_attn_k, sa.self_attn_v]).bias is None
+    # device moves drop the cache (checked with the CPU move, which needs no GPU)
+    f4 = ca.fused_kv()
+    W.to_cpu()
+    assert ca.fused_kv() is not f4
+
+
+def test_attention_plugins_refuse_varlen_descriptions_they_would_ignore():
+    a = L.ATTN_WEIGHT_REGISTER["hip_flash_attn"]()
+    q = torch.zeros(8, 1, 128, dtype=torch.bfloat16)
+    with pytest.raises(ValueError, match="does not cover"):
+        a.apply(q, q, q, cu_seqlens_q=torch.tensor([0, 8]), cu_seqlens_kv=torch.tensor([0, 6]))
+    with pytest.raises(ValueError, match="max_seqlen"):
+        a.apply(q, q, q, max_seqlen_q=8, max_seqlen_kv=6)
+    with pytest.raises(NotImplementedError, match="one sequence"):
+        a.apply(q, q, q, cu_seqlens_q=torch.tensor([0, 4, 8]))
+
+
+def test_options_roundtrip_and_reject_unknown_names():
+    assert hip.get_option("attn_kernel") in (16, 4, 8)
+    old = hip.get_option("attn_round_sync")
+    hip.set_option("attn_round_sync", 0)
+    assert hip.get_option("attn_round_sync") == 0
+    hip.set_option("attn_round_sync", old)
+    with pytest.raises(hip.Lx2vError, match="unknown option"):
+        hip.set_option("no_such_option", 1)
+    with pytest.raises(hip.Lx2vError, match="attn_qb"):
+        hip.set_option("attn_qb", 7)
+

@@ -105,7 +105,7 @@ def test_gemm_bias(cuda, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(4000, 2048, 2048, "none"), (1111, 1536, 8960, "gelu"), (3000, 5120, 5120, "resid"), (700, 512, 192, "none")])
-def test_gemm_schedules_agree_bitwise(cuda, M, N, K, epi, monkeypatch):
+def test_gemm_schedules_agree_bitwise(cuda, M, N, K, epi, options):
     """The ping-pong schedule accumulates every output in the same order as the one-barrier
     schedule, so the two must agree bit for bit -- a stale or early-read LDS tile would not.
     Repeated launches with other work in flight in between (different timing each time)."""
@@ -122,9 +122,9 @@ def test_gemm_schedules_agree_bitwise(cuda, M, N, K, epi, monkeypatch):
             return hip.gemm(ad, wd, bd, epilogue=hip.EPI_RESIDUAL, resid=resid, gate=gate.to(cuda))
         return hip.gemm(ad, wd, bd)
 
-    monkeypatch.setenv("LX2V_GEMM_KERNEL", "simple")
+    options(gemm_kernel=1)  # the simple schedule
     ref = run()
-    monkeypatch.delenv("LX2V_GEMM_KERNEL")
+    options(gemm_kernel=0)
     noise = torch.empty(64 << 20, dtype=torch.uint8, device=cuda)
     for i in range(6):
         if i % 2:
@@ -161,27 +161,51 @@ def test_gemm_epilogues(cuda, M, N, K):
         assert (out.float().cpu() - ref).abs().max().item() <= 2 * BF16_EPS * ref.abs().max().item() + 1e-3
 
 
-def test_gemm_k_segmented_operand(cuda):
+@pytest.mark.parametrize("schedule", [0, 1])
+def test_gemm_k_segmented_operand(cuda, options, schedule):
     """A given as [segments][M][kseg] (the Ulysses receive layout) equals the gathered matrix."""
+    options(gemm_kernel=schedule)
     M, N, kseg, nseg = 130, 256, 128, 4
     segs = _rand((nseg, M, kseg), 17)
     w = _rand((N, kseg * nseg), 18, 0.05)
     a_full = segs.permute(1, 0, 2).reshape(M, nseg * kseg)
     ref = R.linear(a_full.float(), w.float(), None)
     sd = segs.to(cuda)
-    out = hip.gemm(sd.view(nseg * M, kseg)[:M], w.to(cuda), None, a_kseg=kseg, a_kseg_stride=M * kseg)
+    out = hip.gemm(sd.view(nseg * M, kseg)[:M], w.to(cuda), None, kseg=hip.KSeg(seg=kseg, stride=M * kseg))
+    assert (out.float().cpu() - ref).abs().max().item() <= BF16_EPS * ref.abs().max().item() + 1e-3
+
+
+@pytest.mark.parametrize("schedule", [0, 1])
+@pytest.mark.parametrize("M", [130, 700])
+def test_gemm_k_segmented_operand_two_regions(cuda, options, schedule, M):
+    """Head chunks of two widths (5 heads per rank -> 3 + 2): region 1 = `world` segments of
+    3*128 columns, region 2 = `world` segments of 2*128 columns with their own row stride, stored
+    one after the other in one buffer.  Bit-identical to the GEMM on the gathered matrix."""
+    options(gemm_kernel=schedule)
+    world, N = 2, 256
+    w0, w1 = 3 * 128, 2 * 128
+    r1, r2 = _rand((world, M, w0), 27), _rand((world, M, w1), 28)
+    w = _rand((N, world * (w0 + w1)), 29, 0.05)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(30)) * 0.1
+    a_full = torch.cat([r1.permute(1, 0, 2).reshape(M, world * w0), r2.permute(1, 0, 2).reshape(M, world * w1)], dim=1)
+    flat = torch.cat([r1.reshape(-1), r2.reshape(-1)]).to(cuda)
+    ks = hip.KSeg(seg=w0, stride=M * w0, split=world * w0, seg2=w1, stride2=M * w1, base2=world * M * w0, lda2=w1)
+    out = hip.gemm(flat[:M * w0].view(M, w0), w.to(cuda), bias.to(cuda), kseg=ks)
+    plain = hip.gemm(a_full.to(cuda), w.to(cuda), bias.to(cuda))
+    assert torch.equal(out, plain)
+    ref = R.linear(a_full.float(), w.float(), bias)
     assert (out.float().cpu() - ref).abs().max().item() <= BF16_EPS * ref.abs().max().item() + 1e-3
 
 
 @pytest.fixture(params=["x16-4", "x16-5", "w4", "w8"])
-def attn_kernel(request, monkeypatch):
+def attn_kernel(request, options):
     """Every attention kernel of the library behind the one C entry point: the 16x16x32-MFMA
     kernel (one wave per SIMD) with 4 and with 5 query blocks per wave, the 32x32x16 one and the
-    8-wave one (the library reads LX2V_ATTN_KERNEL and LX2V_ATTN_QB on every call)."""
+    8-wave one (options attn_kernel / attn_qb)."""
     name, _, qb = request.param.partition("-")
-    monkeypatch.setenv("LX2V_ATTN_KERNEL", name)
+    options(attn_kernel={"x16": 16, "w4": 4, "w8": 8}[name])
     if qb:
-        monkeypatch.setenv("LX2V_ATTN_QB", qb)
+        options(attn_qb=int(qb))
     return request.param
 
 
@@ -201,18 +225,17 @@ def test_attention_matches_sdpa(cuda, attn_kernel, sq, skv, H):
 
 
 @pytest.mark.parametrize("qb,H", [("4", 4), ("5", 5)])
-def test_attention_short_last_round_goes_to_a_second_launch(cuda, monkeypatch, qb, H):
+def test_attention_short_last_round_goes_to_a_second_launch(cuda, options, qb, H):
     """260 workgroups on a 256-CU part: the four left over after the last full round (the end of
     the last head) are computed by a second launch with 64-row workgroups; every row must come
     out the same as in the single-launch run and match the reference."""
-    monkeypatch.setenv("LX2V_ATTN_KERNEL", "x16")
-    monkeypatch.setenv("LX2V_ATTN_QB", qb)
+    options(attn_kernel=16, attn_qb=int(qb))
     sq, skv = 16640 - 37, 200
     q, k, v = _rand((sq, H, 128), 40), _rand((skv, H, 128), 41), _rand((skv, H, 128), 42)
     ref = R.sdpa(q.float(), k.float(), v.float())
     qd, kd, vd = q.to(cuda), k.to(cuda), v.to(cuda)
     out = hip.attn_fwd(qd, kd, vd)
-    monkeypatch.setenv("LX2V_ATTN_TAIL", "0")
+    options(attn_tail=0)
     one = hip.attn_fwd(qd, kd, vd)
     assert torch.equal(out[: sq - 2048], one[: sq - 2048])
     assert cos(out, ref) >= 0.9999 and cos(one, ref) >= 0.9999

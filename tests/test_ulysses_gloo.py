@@ -21,11 +21,28 @@ def _free_port():
     return port
 
 
-def _torch_pack(q, k, v, world):
+def _torch_pack(q, k, v, world, out=None):
     rows, dim = q.shape
     seg = dim // world
-    st = torch.stack([q, k, v], dim=1).view(rows, 3, world, seg)
-    return st.permute(2, 0, 1, 3).contiguous()
+    st = torch.stack([q, k, v], dim=1).view(rows, 3, world, seg).permute(2, 0, 1, 3)
+    return st.contiguous() if out is None else out.copy_(st)
+
+
+def _logical(op):
+    """Walk a SegmentedOperand the way the GEMM's A cursor does: K column -> (region, segment, column)."""
+    ks, sl = op.kseg, op.sl
+    K = sum(op.widths) * op.world * op.d
+    flat = op.flat
+    cols = []
+    for kcol in range(0, K, 64):
+        if ks.split == 0 or kcol < ks.split:
+            s_, c_ = divmod(kcol, ks.seg)
+            base, lda = s_ * ks.stride + c_, ks.seg
+        else:
+            s_, c_ = divmod(kcol - ks.split, ks.seg2)
+            base, lda = ks.base2 + s_ * ks.stride2 + c_, ks.lda2
+        cols.append(torch.stack([flat[base + m * lda: base + m * lda + 64] for m in range(sl)]))
+    return torch.cat(cols, dim=1)
 
 
 class _OracleAttn:
@@ -33,7 +50,7 @@ class _OracleAttn:
         return R.sdpa(q.float(), k.float(), v.float()).to(q.dtype)
 
 
-def _worker(rank, world, port, cfg_p, seq_p, out_dir):
+def _worker(rank, world, port, cfg_p, seq_p, out_dir, heads_per_rank=2, chunks=2):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -41,7 +58,8 @@ def _worker(rank, world, port, cfg_p, seq_p, out_dir):
 
     cfg_idx, seq_idx, seq_group, cfg_group = ulysses.make_groups(cfg_p, seq_p)
     assert rank == cfg_idx * seq_p + seq_idx
-    S, H, d = 8 * seq_p, 2 * seq_p, 128
+    os.environ["LX2V_ULYSSES_CHUNKS"] = str(chunks)
+    S, H, d = 8 * seq_p, heads_per_rank * seq_p, 128
     g = torch.Generator().manual_seed(100 + cfg_idx)  # cond / uncond branches see different data
     q, k, v = (torch.randn(S, H, d, generator=g) for _ in range(3))
     ql, kl, vl = (t.chunk(seq_p)[seq_idx].contiguous() for t in (q, k, v))
@@ -52,13 +70,9 @@ def _worker(rank, world, port, cfg_p, seq_p, out_dir):
     ref = R.sdpa(q, k, v).chunk(seq_p)[seq_idx]
     err = (out - ref).abs().max().item()
     # zero-copy form: logical matrix [Sl, H*d] described by K segments
-    buf, kseg, kstride = uly.apply_segmented(ql, kl, vl, attention_module=_OracleAttn(), seq_p_group=seq_group)
-    flat = buf.reshape(-1) if buf.is_contiguous() else None
-    base = buf.storage_offset()
-    nseg = H * d // kseg  # seq_p ranks x head chunks per rank
-    storage = torch.as_strided(buf, (nseg * Sl * kseg,), (1,), base)
-    logical = torch.stack([storage[s * kstride:(s * kstride + Sl * kseg)].view(Sl, kseg) for s in range(nseg)], dim=1).reshape(Sl, nseg * kseg)
-    err2 = (logical - ref).abs().max().item()
+    op = uly.apply_segmented(ql, kl, vl, attention_module=_OracleAttn(), seq_p_group=seq_group)
+    assert op.widths == ulysses.split_heads(heads_per_rank, chunks) and op.first.shape == (Sl, op.widths[0] * d)
+    err2 = max((_logical(op) - ref).abs().max().item(), (op.gathered() - ref).abs().max().item())
     # H not divisible by N must raise, not floor silently
     raised = False
     try:
@@ -84,10 +98,13 @@ def _worker(rank, world, port, cfg_p, seq_p, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("cfg_p,seq_p", [(1, 2), (2, 2), (1, 4)])
-def test_ulysses_and_cfg_groups_gloo(tmp_path, cfg_p, seq_p):
+@pytest.mark.parametrize("cfg_p,seq_p,heads_per_rank,chunks", [(1, 2, 2, 2), (2, 2, 2, 2), (1, 4, 2, 2),
+                                                              (1, 2, 5, 2),    # 5 heads per rank -> chunks of 3 + 2 (14B at seq_p = 8)
+                                                              (1, 2, 5, 3),    # 2 + 2 + 1
+                                                              (1, 2, 3, 1)])   # one exchange, no overlap
+def test_ulysses_and_cfg_groups_gloo(tmp_path, cfg_p, seq_p, heads_per_rank, chunks):
     world = cfg_p * seq_p
-    mp.spawn(_worker, args=(world, _free_port(), cfg_p, seq_p, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), cfg_p, seq_p, str(tmp_path), heads_per_rank, chunks), nprocs=world, join=True)
     for r in range(world):
         res = torch.load(os.path.join(str(tmp_path), f"r{r}.pt"))
         assert res["err"] < 1e-5 and res["err2"] < 1e-5, res

@@ -13,9 +13,6 @@ def _rank(rank, world, layout, extra):
     os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank), "MASTER_ADDR": "127.0.0.1",
                        "MASTER_PORT": "29541", "LX2V_SHARE_GPU": "1", "LX2V_DIST_BACKEND": "gloo"})
     os.environ.setdefault("LX2V_BENCH_WATCHDOG", "150")
-    # gloo moving CUDA tensors of >2 processes that share one GPU stalls on back-to-back all-to-alls;
-    # the chunked exchange itself is covered by tests/test_ulysses_gloo.py and tests/test_dist_gpu.py
-    os.environ.setdefault("LX2V_ULYSSES_CHUNKS", "1")
     sys.path.insert(0, ROOT)
     sys.argv = ["bench.py", "--gpus", str(world), "--layout", layout] + extra
     import bench
