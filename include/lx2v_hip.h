@@ -197,6 +197,23 @@ int lx2v_attn_fwd_fp8(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t
                       int64_t sq, int64_t skv, int heads, int head_dim, float scale,
                       void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- lx2v_attn_fwd_fp8 for callers that cannot allocate ---------------------------------------
+ * No counterpart in the reference.  It is for callers that cannot call hipMalloc or hand over a
+ * workspace: code under HIP graph capture, tight serving loops, harnesses that forbid allocation.
+ * Same computation and results as lx2v_attn_fwd_fp8, with the quantised q / K / V images in a fixed
+ * array of LX2V_ATTN_FP8_STATIC_BYTES that every GPU the library runs on holds until the process
+ * ends.  Shapes with lx2v_attn_fp8_workspace_bytes(sq, skv, heads) above that size are rejected
+ * with LX2V_EUNSUP (e.g. 12 heads x 4 680 tokens need 22.6 MB; use lx2v_attn_fwd_fp8 beyond).
+ * Calls no allocating routine.  All calls on one GPU share that GPU's array: calls that overlap on
+ * one GPU (two streams, two threads) race; calls on one stream are ordered.  Nothing in the array
+ * has to start at zero (the pre-pass of a call writes every byte its kernels read). */
+#define LX2V_ATTN_FP8_STATIC_BYTES (32 << 20)
+int64_t lx2v_attn_fp8_static_bytes(void);
+int lx2v_attn_fwd_fp8_static(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk,
+                             const uint16_t* v, int64_t ldv, uint16_t* out, int64_t ldo,
+                             int64_t sq, int64_t skv, int heads, int head_dim, float scale,
+                             void* stream);
+
 /* ==== fp8 (OCP e4m3) W8A8 Linear on the CDNA4 fp8 MFMA ===================================== */
 
 /* ---- row-wise dynamic quantisation: scale[r] = max|x[r,:]| / 448 ; out[r,:] = e4m3(x[r,:] / scale[r]) ----

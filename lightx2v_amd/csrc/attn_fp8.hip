@@ -24,6 +24,8 @@
 // every scale sits in the byte an immediate `opsel` picks, so no lane extracts one); staging a tile
 // is a linear copy, done by LDS-DMA.  Workgroup = 8 waves x 32 query rows; the blobs are
 // double-buffered in LDS, tile t+1 is in flight while tile t is consumed.
+#include <mutex>
+
 #include "attn_common.h"
 
 using namespace lx2v_attn;
@@ -383,9 +385,11 @@ extern "C" int64_t lx2v_attn_fp8_workspace_bytes(int64_t sq, int64_t skv, int he
   return q + (int64_t)heads * tiles_of(skv) * TILE_BLOB;
 }
 
-extern "C" int lx2v_attn_fwd_fp8(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* v, int64_t ldv,
-                                 uint16_t* out, int64_t ldo, int64_t sq, int64_t skv, int heads, int head_dim, float scale,
-                                 void* workspace, int64_t workspace_bytes, void* stream) {
+// Pre-pass + attention over `workspace` (device memory of at least lx2v_attn_fp8_workspace_bytes
+// bytes, every byte the kernels read is written by the pre-pass of the same call).
+static int attn_fwd_fp8_on(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* v, int64_t ldv,
+                           uint16_t* out, int64_t ldo, int64_t sq, int64_t skv, int heads, int head_dim, float scale,
+                           void* workspace, int64_t workspace_bytes, void* stream) {
   LX2V_REQUIRE(sq == 0 || (q && k && v && out && workspace), LX2V_EINVAL, "attn_fwd_fp8: null tensor");
   LX2V_REQUIRE(head_dim == HD, LX2V_EUNSUP, "attn_fwd_fp8: head_dim=%d, only 128 is built", head_dim);
   LX2V_REQUIRE(heads > 0 && sq >= 0 && skv >= 0, LX2V_EINVAL, "attn_fwd_fp8: bad shape sq=%lld skv=%lld heads=%d", (long long)sq, (long long)skv, heads);
@@ -423,4 +427,55 @@ extern "C" int lx2v_attn_fwd_fp8(const uint16_t* q, int64_t ldq, const uint16_t*
   else hipLaunchKernelGGL(attn_fwd_fp8_kernel<false>, dim3((unsigned)nwg), dim3(NTHREADS), 0, st, p);
   LX2V_CHECK_LAUNCH("attn_fwd_fp8");
   return LX2V_OK;
+}
+
+extern "C" int lx2v_attn_fwd_fp8(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* v, int64_t ldv,
+                                 uint16_t* out, int64_t ldo, int64_t sq, int64_t skv, int heads, int head_dim, float scale,
+                                 void* workspace, int64_t workspace_bytes, void* stream) {
+  return attn_fwd_fp8_on(q, ldq, k, ldk, v, ldv, out, ldo, sq, skv, heads, head_dim, scale, workspace, workspace_bytes, stream);
+}
+
+// ---- the variant that allocates nothing: the quantised q / K / V images go to a fixed array ----
+// Each GPU the library runs on holds its own copy of `scratch` (at its own address) until the
+// process ends.  In host code the array's name is only a stand-in for that memory: its address on
+// the current device comes from hipGetSymbolAddress, once per device, and everything below uses
+// that pointer.
+static __device__ __align__(256) unsigned char scratch[LX2V_ATTN_FP8_STATIC_BYTES];
+
+static int static_scratch_of_current_device(unsigned char** ptr_out) {
+  static std::mutex mu;
+  static unsigned char* ptr_of[64];  // per device
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+    lx2v_set_error("attn_fwd_fp8_static: hipGetDevice failed or device index %d out of range", dev);
+    return LX2V_EHIP;
+  }
+  std::lock_guard<std::mutex> lock(mu);
+  if (ptr_of[dev] == nullptr) {
+    unsigned char* ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || ptr == nullptr) {
+      lx2v_set_error("attn_fwd_fp8_static: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+      return LX2V_EHIP;
+    }
+    ptr_of[dev] = ptr;
+  }
+  *ptr_out = ptr_of[dev];
+  return LX2V_OK;
+}
+
+extern "C" int64_t lx2v_attn_fp8_static_bytes(void) { return LX2V_ATTN_FP8_STATIC_BYTES; }
+
+extern "C" int lx2v_attn_fwd_fp8_static(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* v, int64_t ldv,
+                                        uint16_t* out, int64_t ldo, int64_t sq, int64_t skv, int heads, int head_dim, float scale,
+                                        void* stream) {
+  const int64_t need = lx2v_attn_fp8_workspace_bytes(sq, skv, heads);
+  LX2V_REQUIRE(need >= 0, LX2V_EINVAL, "attn_fwd_fp8_static: bad shape sq=%lld skv=%lld heads=%d", (long long)sq, (long long)skv, heads);
+  LX2V_REQUIRE(need <= (int64_t)LX2V_ATTN_FP8_STATIC_BYTES, LX2V_EUNSUP,
+               "attn_fwd_fp8_static: sq=%lld skv=%lld heads=%d needs %lld bytes of scratch, the fixed array holds %lld; use lx2v_attn_fwd_fp8 with a workspace",
+               (long long)sq, (long long)skv, heads, (long long)need, (long long)LX2V_ATTN_FP8_STATIC_BYTES);
+  unsigned char* ptr = nullptr;
+  const int rc = static_scratch_of_current_device(&ptr);
+  if (rc != LX2V_OK) return rc;
+  return attn_fwd_fp8_on(q, ldq, k, ldk, v, ldv, out, ldo, sq, skv, heads, head_dim, scale, ptr, LX2V_ATTN_FP8_STATIC_BYTES, stream);
 }

@@ -37,6 +37,8 @@ _SIGNATURES = {
     "lx2v_cfg_combine_f32": [_P, _P, _P, _F, _I64, _P],
     "lx2v_attn_fp8_workspace_bytes": [_I64, _I64, _I],
     "lx2v_attn_fwd_fp8": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I, _I, _F, _P, _I64, _P],
+    "lx2v_attn_fp8_static_bytes": [],
+    "lx2v_attn_fwd_fp8_static": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I, _I, _F, _P],
     "lx2v_set_option": [ctypes.c_char_p, _I],
     "lx2v_get_option": [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)],
     "lx2v_quant_fp8_rowwise": [_P, _I64, _P, _I64, _P, _I64, _I, _P],
@@ -65,7 +67,7 @@ def load() -> ctypes.CDLL:
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_int64 if name in ("lx2v_attn_fp8_workspace_bytes",) else ctypes.c_int
+        fn.restype = ctypes.c_int64 if name in ("lx2v_attn_fp8_workspace_bytes", "lx2v_attn_fp8_static_bytes") else ctypes.c_int
     lib.lx2v_abi_version.restype = ctypes.c_int
     lib.lx2v_last_error.restype = ctypes.c_char_p
     _lib = lib
@@ -294,6 +296,30 @@ def attn_fwd_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optio
                                   sq, skv, H, d, float(scale), workspace.data_ptr(), workspace.numel(), _stream())
     _check(st, "lx2v_attn_fwd_fp8")
     return out
+
+
+def attn_fwd_fp8_static(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, scale: Optional[float] = None) -> torch.Tensor:
+    """`attn_fwd_fp8` through the entry point that allocates nothing: the caller brings `out`, the
+    quantised images live in the library's fixed per-GPU array (shapes beyond it raise)."""
+    for n, t in (("q", q), ("k", k), ("v", v)):
+        _need_bf16_cuda("attn_fp8_static." + n, t)
+        if t.dim() != 3 or t.stride(1) != t.shape[2]:
+            raise Lx2vError(f"attn_fp8_static.{n}: expected [S,H,d] with heads contiguous inside a token, got shape {tuple(t.shape)} strides {t.stride()}")
+    sq, H, d = q.shape
+    skv = k.shape[0]
+    if k.shape[1:] != (H, d) or v.shape != k.shape:
+        raise Lx2vError(f"attn_fp8_static: q {tuple(q.shape)} k {tuple(k.shape)} v {tuple(v.shape)} do not agree")
+    _need_out("attn_fp8_static.out", out, (sq, H * d), q)
+    if scale is None:
+        scale = d ** -0.5
+    st = load().lx2v_attn_fwd_fp8_static(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), out.data_ptr(), out.stride(0),
+                                         sq, skv, H, d, float(scale), _stream())
+    _check(st, "lx2v_attn_fwd_fp8_static")
+    return out
+
+
+def attn_fp8_static_bytes() -> int:
+    return int(load().lx2v_attn_fp8_static_bytes())
 
 
 def attn_fp8_workspace_bytes(sq: int, skv: int, heads: int) -> int:

@@ -221,3 +221,13 @@ def test_options_roundtrip_and_reject_unknown_names():
     with pytest.raises(hip.Lx2vError, match="attn_qb"):
         hip.set_option("attn_qb", 7)
 
+
+def test_static_scratch_entry_point_rejects_oversize_without_touching_the_gpu():
+    lib = hip.load()
+    cap = hip.attn_fp8_static_bytes()
+    assert cap == 32 << 20
+    assert hip.attn_fp8_workspace_bytes(4680, 4680, 12) <= cap < hip.attn_fp8_workspace_bytes(32760, 32760, 12)
+    buf = ctypes.create_string_buffer(4096 + 16)
+    p = (ctypes.addressof(buf) + 15) & ~15
+    assert lib.lx2v_attn_fwd_fp8_static(p, 1536, p, 1536, p, 1536, p, 1536, 32760, 32760, 12, 128, 0.1, None) == -2
+    assert b"fixed array" in lib.lx2v_last_error()
