@@ -33,10 +33,10 @@ const char* lx2v_last_error(void);
 
 /* ---- kernel-selection switches -------------------------------------------------------------
  * Named integer options, initialised once from the environment (LX2V_ATTN_KERNEL, LX2V_ATTN_QB,
- * LX2V_ATTN_TAIL, LX2V_ATTN_ROUND_SYNC, LX2V_ATTN_VARIANT, LX2V_GEMM_KERNEL, LX2V_GEMM_PERSISTENT)
+ * LX2V_ATTN_TAIL, LX2V_ATTN_ROUND_SYNC, LX2V_ATTN_VARIANT, LX2V_GEMM_KERNEL)
  * and changeable at run time; launches read them, never the environment.  Names: "attn_kernel"
  * (16 | 4 | 8), "attn_qb" (0 | 4 | 5), "attn_tail", "attn_round_sync", "attn_variant" (0 | 1),
- * "gemm_kernel" (0 default | 1 simple | 2 ping-pong), "gemm_persistent" (0 | 1).  Every setting
+ * "gemm_kernel" (0 default | 1 one barrier per K-tile | 2 ping-pong).  Every setting
  * computes the same function; they exist for A/B timing and for tests.  Not to be changed while
  * another thread launches.  Stands where the reference selects a backend by registry name
  * (lightx2v/utils/registry_factory.py:1-56): these choose among kernels behind ONE name. */

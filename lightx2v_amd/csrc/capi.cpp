@@ -41,7 +41,6 @@ void init_options() {
   g_opt.attn_variant = env_int("LX2V_ATTN_VARIANT", 1) != 0;
   const char* g = getenv("LX2V_GEMM_KERNEL");
   g_opt.gemm_kernel = g == nullptr ? 0 : strcmp(g, "simple") == 0 ? 1 : strcmp(g, "pingpong") == 0 ? 2 : 0;
-  g_opt.gemm_persistent = env_int("LX2V_GEMM_PERSISTENT", 1) != 0;
 }
 
 struct OptName {
@@ -52,7 +51,6 @@ const OptName kOptNames[] = {
     {"attn_kernel", &Lx2vOptions::attn_kernel}, {"attn_qb", &Lx2vOptions::attn_qb},
     {"attn_tail", &Lx2vOptions::attn_tail},     {"attn_round_sync", &Lx2vOptions::attn_round_sync},
     {"attn_variant", &Lx2vOptions::attn_variant}, {"gemm_kernel", &Lx2vOptions::gemm_kernel},
-    {"gemm_persistent", &Lx2vOptions::gemm_persistent},
 };
 
 }  // namespace

@@ -17,74 +17,11 @@
 
 #include <type_traits>
 
-#include "common.h"
+#include "gemm_bf16_common.h"
 
 namespace {
 
-constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int NTHREADS = 512;
-constexpr int TILE_BYTES = BM * BK * 2;  // 32 KiB, same for A and W
-constexpr int GROUP_M = 8;               // tile rasterisation: 8 row-panels share one column sweep
-#ifndef GEMM_ABL
-#define GEMM_ABL 0  // timing ablations (wrong results): 1 no load wait, 2 no staging, 4 no barrier, 8 no priority raise (ping-pong), 16 no fragment reads (ping-pong), 32 no epilogue (ping-pong)
-#endif
-
-struct GemmParams {
-  const uint16_t* A;
-  const uint16_t* W;
-  const float* bias;
-  uint16_t* C;
-  const uint16_t* resid;
-  const float* gate;
-  int64_t lda, ldw, ldc, ldr;
-  int64_t a_kseg, a_kseg_stride;  // a_kseg == 0: plain matrix
-  int64_t a_split, a_kseg2, a_kseg2_stride, a_base2, lda2;  // a_split > 0: from K column a_split on, segments of a_kseg2 columns starting at A + a_base2, row stride lda2
-  int M, N, K;
-  int tiles_m, tiles_n;
-};
-
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void gbl_void;
-
-LX2V_DEVICE void glds16(const void* g, void* l) {
-  __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)l, 16, 0, 0);
-}
-
-// Position of a K-tile inside A when A's columns are stored as segments (see lx2v_kseg): `koff` is
-// the element offset of the tile from the row start; advance() moves one K-tile on.  All fields are
-// wave-uniform.
-struct ACursor {
-  int64_t koff = 0, within = 0, kpos = 0, seg, stride;
-  LX2V_DEVICE explicit ACursor(const GemmParams& p) : seg(p.a_kseg), stride(p.a_kseg_stride) {}
-  // Returns true when the cursor has just entered region 2 (the caller then switches its per-lane
-  // row offsets from lda to lda2).
-  LX2V_DEVICE bool advance(const GemmParams& p) {
-    koff += BK;
-    if (p.a_kseg != 0) {
-      within += BK;
-      kpos += BK;
-      if (kpos == p.a_split) {  // never true for a_split == 0 (kpos >= BK)
-        koff = p.a_base2;
-        within = 0;
-        seg = p.a_kseg2;
-        stride = p.a_kseg2_stride;
-        return true;
-      }
-      if (within == seg) {
-        within = 0;
-        koff += stride - seg;
-      }
-    }
-    return false;
-  }
-};
-
-// Bijective remap so that blocks sharing an XCD (same blockIdx % 8) get a contiguous run of tiles.
-LX2V_DEVICE int xcd_remap(int bid, int nwg) {
-  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return base + (bid >> 3);
-}
 
 // Epilogue shared by both schedules: fp32 math on the accumulators -> per-wave LDS image (bf16) ->
 // whole 128-B row segments.  acc[nt][mt][j] = C'[m = wm*128 + mt*16 + fr][n = wn*64 + nt*16 + fq*4 + j].
@@ -474,6 +411,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_pp_kernel(const GemmParams
 
 }  // namespace
 
+int lx2v_gemm_launch_w4(lx2v_gemm::GemmParams& p, int epilogue, hipStream_t st);  // gemm_bf16_w4.hip
+
 extern "C" int lx2v_gemm_bf16(const uint16_t* A, int64_t lda, const lx2v_kseg* kseg,
                               const uint16_t* W, int64_t ldw, const float* bias,
                               uint16_t* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
@@ -518,9 +457,30 @@ extern "C" int lx2v_gemm_bf16(const uint16_t* A, int64_t lda, const lx2v_kseg* k
   p.tiles_n = (int)((N + BN - 1) / BN);
   const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
   LX2V_REQUIRE(nwg < (1LL << 31), LX2V_EUNSUP, "gemm: too many tiles");
+  // extents, for the bounds of the buffer descriptors the persistent kernel stages through
+  int64_t a_end = (M - 1) * lda + K;
+  if (ks.seg != 0) {
+    const int64_t k1 = ks.split > 0 ? ks.split : K;
+    a_end = (k1 / ks.seg - 1) * ks.stride + (M - 1) * lda + ks.seg;
+    if (ks.split > 0) {
+      const int64_t e2 = ks.base2 + ((K - ks.split) / ks.seg2 - 1) * ks.stride2 + (M - 1) * ks.lda2 + ks.seg2;
+      a_end = e2 > a_end ? e2 : a_end;
+    }
+  }
+  p.a_bytes = a_end * 2;
+  p.w_bytes = ((N - 1) * ldw + K) * 2;
   const dim3 grid((unsigned)nwg), block(NTHREADS);
   hipStream_t st = (hipStream_t)stream;
-  const bool simple = lx2v_options().gemm_kernel == 1;  // the one-barrier-per-K-tile schedule (A/B switch)
+  // Kernel choice (option gemm_kernel): 0 = the persistent one-wave-per-SIMD kernel, 1 = 8 waves with
+  // one barrier per K-tile, 2 = 8 waves in the ping-pong schedule.  All three give identical results.
+  const int which = lx2v_options().gemm_kernel;
+  if (which == 0 && p.a_bytes < (1LL << 32) && p.w_bytes < (1LL << 32)) {
+    const int rc = lx2v_gemm_launch_w4(p, epilogue, st);
+    if (rc != LX2V_OK) return rc;
+    LX2V_CHECK_LAUNCH("gemm(persistent)");
+    return LX2V_OK;
+  }
+  const bool simple = which == 1;
   if (simple || K < 2 * BK) {
     switch (epilogue) {
       case LX2V_EPI_NONE: hipLaunchKernelGGL(gemm_bf16_kernel<LX2V_EPI_NONE>, grid, block, 0, st, p); break;

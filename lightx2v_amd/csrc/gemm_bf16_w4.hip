@@ -1,0 +1,435 @@
+// bf16 Linear on MFMA, persistent, one wave per SIMD:  C[M,N] = epilogue(A[M,K] @ W[N,K]^T + bias).
+//
+// Workgroup = 4 waves (2 x 2), one per SIMD, each owning a 128 x 128 corner of a 256 x 256 output
+// tile: 64 accumulator tuples (60 of them in the accumulator half of the 512-entry register file),
+// so a K-step of 32 is 64 independent v_mfma_f32_16x16x32_bf16 against 16 fragment reads -- a
+// third fewer LDS bytes per MFMA than the 128 x 64 corners of the 8-wave kernels.  One workgroup
+// per CU; the grid is one workgroup per CU and every workgroup walks its share of the output
+// tiles, so the stream of K-tiles never drains between tiles: the loads of a tile's first K-tiles
+// fly during the previous tile's epilogue.
+//
+// LDS: a ring of five 32 KiB slots, one operand's K-tile each (all 160 KiB of the CU).  The stream
+// of half-tiles h = 2 j + o (o = 0: A of K-tile j, o = 1: W of K-tile j) goes through slot h % 5.
+// Per K-tile j, two K-steps of 64 MFMAs each:
+//   step 0:  MFMAs on the fragments of (j, 0), read a K-step earlier; the 16 fragment reads of
+//            (j, 1); the 8 LDS-DMA instructions of half-tile 2j + 4 (A of K-tile j + 2) into the
+//            slot W(j - 1) left at the previous barrier.
+//   X:       s_waitcnt vmcnt(8) lgkmcnt(0); s_barrier -- all of this wave's DMA but the 8 just issued
+//            has landed (so K-tile j + 1 is complete) and its reads of K-tile j are done; behind
+//            the barrier that holds for every wave.
+//   step 1:  MFMAs on (j, 1); fragment reads of (j + 1, 0); the 8 DMA instructions of half-tile
+//            2j + 5 (W of K-tile j + 2) into the slot of A(j).
+// So the DMA is issued at a constant rate (one instruction per 8 MFMAs per wave), a half-tile has
+// one to one and a half K-tiles of MFMAs to land, there is one barrier per K-tile, no LDS latency
+// in front of an MFMA and nothing but MFMAs on the vector pipe inside the loop.  During step 1 of
+// K-tile j the slot of W(j) is idle: when j closes an output tile, the epilogue stages through it.
+// The slot images are the 128-byte-row images of the 8-wave kernels (chunk ^= (row >> 1) & 7 on
+// the DMA's source address and on the read).
+//
+// Staging is `buffer_load_dwordx4 ... lds` against raw buffer descriptors of the tile's row panels:
+// rows past M (or N) are out of the descriptor's range and arrive as zeros.  The DMA and the MFMAs
+// are asm statements (MFMA operands in the accumulator half need explicit register classes; an
+// LDS-DMA the compiler knows about would make it drain vmcnt before LDS reads), so their order in
+// the source is their order in the wave.
+//
+// Epilogue per wave, eight passes of 16 rows: the accumulator tuples go to LDS as fp32 straight
+// from the accumulator file, come back as eight consecutive columns per lane, get bias / GELU /
+// gate in fp32 and leave as whole 256-byte row segments of bf16 (residual read the same way, one
+// pass ahead).
+#include "gemm_bf16_common.h"
+
+namespace {
+
+#ifndef W4_ABL
+#define W4_ABL 0  // timing ablations (wrong results): 1 no LDS-DMA in the loop, 2 no fragment reads, 4 no wait + barrier per K-tile, 8 no epilogue, 16 no MFMAs, 32 wait for the DMA only (no barrier), 64 barrier only (no waits)
+#endif
+constexpr int W4_THREADS = 256;
+constexpr int NSLOT = 5;                      // ring of operand K-tiles
+constexpr int W4_LDS = NSLOT * TILE_BYTES;    // all 160 KiB of the CU
+
+struct Frag {
+  u32x4 a[8];  // activations, rows wm*128 + mt*16 + (lane & 15), 8 bf16 of chunk 4 ks + (lane >> 4)
+  u32x4 w[8];  // weights, rows wn*128 + nt*16 + (lane & 15)
+};
+
+// acc += W fragment (MFMA A operand: output columns) x A fragment (B operand: rows).  60 of the 64
+// accumulator tuples live in the accumulator half of the register file, the last four (nt = 7,
+// mt >= 4) in the architectural half: the compiler keeps a few accumulator registers to itself,
+// and asked for all 256 it spills tuples inside the loop.
+// FIRST: the K-step that opens an output tile starts its accumulators from 0.
+template <bool IN_AGPR, bool FIRST>
+LX2V_DEVICE void mfma_acc(f32x4& acc, const u32x4& wf, const u32x4& af) {
+  if constexpr (W4_ABL & 16) {
+    asm volatile("" ::"v"(wf), "v"(af));
+  } else if constexpr (FIRST) {
+    if constexpr (IN_AGPR) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc) : "v"(wf), "v"(af));
+    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(wf), "v"(af));
+  } else {
+    if constexpr (IN_AGPR) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(wf), "v"(af));
+    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(wf), "v"(af));
+  }
+}
+constexpr bool acc_in_agpr(int nt, int mt) { return !(nt == 7 && mt >= 4); }
+// An accumulator tuple leaves its file as the data operand of an LDS write (DS instructions take
+// accumulator registers directly), so every use of those tuples is an asm statement with the
+// accumulator register class and the register allocator has no reason to re-home them (given
+// ordinary reads it copies all of them out in front of the epilogue and pays for the registers
+// with spills inside the K-loop).
+template <bool IN_AGPR>
+LX2V_DEVICE void acc_to_lds(int lds_addr, const f32x4& acc) {
+  if constexpr (IN_AGPR) asm volatile("ds_write_b128 %0, %1" ::"v"(lds_addr), "a"(acc) : "memory");
+  else asm volatile("ds_write_b128 %0, %1" ::"v"(lds_addr), "v"(acc) : "memory");
+}
+template <int NT, int MT>
+LX2V_DEVICE void pin_acc(f32x4& acc) {
+  if constexpr (acc_in_agpr(NT, MT)) asm volatile("" : "+a"(acc));
+  else asm volatile("" : "+v"(acc));
+}
+
+LX2V_DEVICE u32x4 raw_descriptor(const void* base, int64_t bytes) {
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  u32x4 d;
+  d[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+  d[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));  // stride 0: raw buffer
+  d[2] = __builtin_amdgcn_readfirstlane((uint32_t)(bytes < 0 ? 0 : (bytes > 0xffffffffLL ? 0xffffffffLL : bytes)));  // loads at or past it return 0
+  d[3] = 0x00020000u;
+  return d;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(W4_THREADS) void gemm_bf16_w4_kernel(const GemmParams p) {
+  __shared__ __attribute__((aligned(16))) char lds[W4_LDS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int grid = gridDim.x;
+  const int nk = p.K / BK;
+
+  // ---- staging: DMA instruction i (0..7) of an operand fills rows 32 i + 8 wid .. + 7 of the tile
+  // image (1 KiB of LDS, lane L the 16 bytes at 16 L: row 8 wid + (L >> 3) + 32 i, position L & 7
+  // holding source chunk (L & 7) ^ ((row >> 1) & 7); the key does not depend on i).
+  const int srow = 8 * wid + (lane >> 3);
+  const int schunk = (lane & 7) ^ ((srow >> 1) & 7);
+  int a_voff = 0;                                                // set with the A descriptor (row stride of the region)
+  const int w_voff = (int)(srow * p.ldw * 2) + schunk * 16;
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)lds);
+  const uint32_t dma_base = lds_base + 1024 * (uint32_t)wid;
+
+  // DMA cursor: the K-tile staged next, two K-tiles ahead of the one computed.
+  int d_ord = 0;                       // ordinal of the cursor's output tile in this workgroup's list
+  int d_kt = 0;
+  ACursor d_cur(p);
+  int d_region = 0;
+  u32x4 a_rs, w_rs;
+  uint32_t a_istep = 0, w_istep = (uint32_t)(32 * p.ldw * 2);
+  // Descriptors of the cursor's tile (and A region).  Past the workgroup's last tile they are
+  // empty (0 bytes): the DMA instructions of the stream's last two K-tiles then fetch nothing and
+  // write zeros into a stage nobody reads, so the loop body needs no "last tiles" variants.
+  auto d_panel = [&]() __attribute__((always_inline)) {
+    const int vbid = d_ord * grid + (int)blockIdx.x;
+    const bool live = vbid < ntiles;
+    int m0 = 0, n0 = 0;
+    if (live) tile_origin(p, vbid, m0, n0);
+    const int64_t ld = d_region ? p.lda2 : p.lda;
+    a_rs = raw_descriptor(p.A + (int64_t)m0 * ld, live ? p.a_bytes - (int64_t)m0 * ld * 2 : 0);
+    a_istep = (uint32_t)(32 * ld * 2);
+    a_voff = (int)(srow * ld * 2) + schunk * 16;
+    w_rs = raw_descriptor(p.W + (int64_t)n0 * p.ldw, live ? p.w_bytes - (int64_t)n0 * p.ldw * 2 : 0);
+  };
+  d_panel();
+
+  // One DMA instruction: lane L's 16 bytes from rsrc + voff + soff to LDS byte m0 + 16 L.
+  auto dma_m0 = [&](uint32_t slot_base, auto dstc) __attribute__((always_inline)) {  // M0 = slot base + constant
+    asm volatile("s_add_u32 m0, %0, %1" ::"s"(slot_base), "i"(decltype(dstc)::value) : "memory", "scc");
+  };
+  auto dma_go = [&](const u32x4& rsrc, int voff, uint32_t soff) __attribute__((always_inline)) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  };
+  // The cursor's half-tile (d_half = 0: A, 1: W) in 8 pieces; piece q fills rows 32 q + 8 wid .. + 7
+  // of the slot at LDS byte `slot_base` (which includes this wave's 1 KiB share).
+  int d_half = 0;
+  uint32_t d_asoff = 0, d_wsoff = 0;  // scalar byte offsets of the cursor's K-tile
+  auto d_begin = [&]() __attribute__((always_inline)) {
+    d_asoff = (uint32_t)(d_cur.koff * 2);
+    d_wsoff = (uint32_t)d_kt * (BK * 2);
+  };
+  auto dma_piece_a = [&](uint32_t slot_base, auto qc) __attribute__((always_inline)) {
+    constexpr int q = decltype(qc)::value;
+    dma_m0(slot_base, IntC<4096 * q>{});
+    asm volatile("s_nop 0");
+    dma_go(a_rs, a_voff, d_asoff + (uint32_t)q * a_istep);
+  };
+  auto dma_piece_w = [&](uint32_t slot_base, auto qc) __attribute__((always_inline)) {
+    constexpr int q = decltype(qc)::value;
+    dma_m0(slot_base, IntC<4096 * q>{});
+    asm volatile("s_nop 0");
+    dma_go(w_rs, w_voff, d_wsoff + (uint32_t)q * w_istep);
+  };
+  auto d_advance = [&]() __attribute__((always_inline)) {  // after the W half of a K-tile
+    ++d_kt;
+    if (d_kt == nk) {
+      d_kt = 0;
+      ++d_ord;
+      d_cur = ACursor(p);
+      d_region = 0;
+      d_panel();
+    } else if (d_cur.advance(p)) {
+      d_region = 1;
+      d_panel();
+    }
+  };
+
+  // ---- fragment read offsets inside a slot image, per K-step; mt / nt add 2048 each ----
+  int rd_a[2], rd_w[2];
+  {
+    const int arow = wm * 128 + fr, wrow = wn * 128 + fr;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      rd_a[ks] = arow * 128 + (((ks * 4 + fq) ^ ((arow >> 1) & 7)) << 4);
+      rd_w[ks] = wrow * 128 + (((ks * 4 + fq) ^ ((wrow >> 1) & 7)) << 4);
+    }
+  }
+  // (slot bases are scalars that change every K-tile: one add per operand and K-step)
+  auto read_frag = [&](const char* base, int i) __attribute__((always_inline)) -> u32x4 {
+    return *reinterpret_cast<const u32x4*>(base + i * 2048);
+  };
+
+  f32x4 acc[8][8];  // acc[nt][mt][j] = C'[m = wm*128 + mt*16 + fr][n = wn*128 + nt*16 + fq*4 + j]
+  // (no initialisation: the first K-step of every output tile writes them from 0)
+  Frag f0, f1;  // fragments of K-step 0 / 1 of the current K-tile
+
+  // One K-step: 16 groups of 4 MFMAs on `cur` (W fragment nt = g >> 1, A fragments 4 (g & 1) .. + 3).
+  // The first 8 groups carry the 16 fragment reads of the next K-step into `nxt` (A fragments first:
+  // the next step needs all of them in its first two groups), from the slot images at `na` / `nw`;
+  // every second group issues one piece of the cursor's half-tile into the slot at `dslot`.
+  // (Past the end of the stream the reads return stale bytes that no MFMA uses.)
+  auto kstep = [&](Frag& cur, Frag& nxt, const char* na, const char* nw, uint32_t dslot, auto HALFc, auto FIRSTc) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(FIRSTc)::value != 0;
+    constexpr int HALF = decltype(HALFc)::value;
+    static_for<0, 16>([&](auto gc) __attribute__((always_inline)) {
+      constexpr int g = decltype(gc)::value, nt = g >> 1, mt0 = 4 * (g & 1);
+      mfma_acc<acc_in_agpr(nt, mt0), FIRST>(acc[nt][mt0], cur.w[nt], cur.a[mt0]);
+      if constexpr ((g & 1) == 0 && !(W4_ABL & 1)) {
+        if constexpr (HALF == 0) dma_piece_a(dslot, IntC<g / 2>{});
+        else dma_piece_w(dslot, IntC<g / 2>{});
+      }
+      mfma_acc<acc_in_agpr(nt, mt0 + 1), FIRST>(acc[nt][mt0 + 1], cur.w[nt], cur.a[mt0 + 1]);
+      if constexpr (W4_ABL & 2) {
+      } else if constexpr (g < 4) {
+        nxt.a[2 * g] = read_frag(na, 2 * g);
+        nxt.a[2 * g + 1] = read_frag(na, 2 * g + 1);
+      } else if constexpr (g < 8) {
+        nxt.w[2 * g - 8] = read_frag(nw, 2 * g - 8);
+        nxt.w[2 * g - 7] = read_frag(nw, 2 * g - 7);
+      }
+      mfma_acc<acc_in_agpr(nt, mt0 + 2), FIRST>(acc[nt][mt0 + 2], cur.w[nt], cur.a[mt0 + 2]);
+      mfma_acc<acc_in_agpr(nt, mt0 + 3), FIRST>(acc[nt][mt0 + 3], cur.w[nt], cur.a[mt0 + 3]);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  // AFTER_EPI: the barrier of the first K-tile behind an epilogue.  The epilogue's 32 stores are
+  // younger than the half-tile that has to have landed and older than the 8 DMA instructions just
+  // issued; memory operations retire in order, so 40 may stay outstanding.  (Only behind an
+  // interior tile: at the M / N edge a wave issues fewer stores, and the count would reach back
+  // into the DMA that has to be complete.)
+  auto sync_x = [&](auto AFTER_EPIc) __attribute__((always_inline)) {
+    if constexpr (W4_ABL & 4) return;
+    if constexpr (!(W4_ABL & 64)) {
+      if constexpr (decltype(AFTER_EPIc)::value != 0 && !(W4_ABL & 128)) asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    }
+    if constexpr (!(W4_ABL & 32)) __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  // ---- epilogue of the output tile at (m0, n0) ----
+  // Eight passes, one per 16-row block mt: the wave's eight tuples of that block go to its 8 KiB of
+  // staging as fp32 (16 rows x 512 B; 16-byte chunk c of row r at position c ^ r), come back as
+  // eight consecutive columns per lane, and leave as whole 256-byte row segments of bf16.
+  auto epilogue = [&](int m0, int n0, int epi_base) __attribute__((always_inline)) {
+    // Lane coordinates behind an opaque statement: everything below that depends only on the lane
+    // would otherwise be computed once in front of the K-loop and sit in registers the loop needs
+    // for its fragments.
+    int fr = lane & 15, fq = lane >> 4;
+    asm volatile("" : "+v"(fr), "+v"(fq));
+    const int stg = (int)(size_t)(__attribute__((address_space(3))) char*)lds + epi_base + wid * 8192;
+    int waddr[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) waddr[nt] = stg + fr * 512 + (((nt * 4 + fq) ^ fr) << 4);
+    const int gn = n0 + wn * 128 + fr * 8;  // this lane's eight output columns
+    const bool col_ok = gn < p.N;           // N % 8 == 0: all eight or none
+    float bv[8], gv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      bv[j] = 0.f;
+      gv[j] = 1.f;
+    }
+    if (col_ok) {
+      if (p.bias != nullptr) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + gn), b1 = *reinterpret_cast<const f32x4*>(p.bias + gn + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bv[j] = b0[j]; bv[4 + j] = b1[j]; }
+      }
+      if (EPI == LX2V_EPI_RESIDUAL && p.gate != nullptr) {
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gate + gn), g1 = *reinterpret_cast<const f32x4*>(p.gate + gn + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { gv[j] = g0[j]; gv[4 + j] = g1[j]; }
+      }
+    }
+    // the last MFMAs were issued a few cycles ago and the LDS writes below read their results
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+    // An unconditional use of the bias / gate registers: their loads are then waited for here, once.
+    // Their only other uses sit in the conditional store blocks below, and a load that is still
+    // pending on the path around such a block makes the compiler wait for ALL memory operations
+    // (vmcnt(0)) in front of every one of them, i.e. for the previous store's completion.
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(bv[j]), "+v"(gv[j]));
+    // Residual rows are loaded one pass ahead (clamped addresses, no branch: the only conditional
+    // operation of a pass is the store), so that no pass waits for its own loads -- a wait for the
+    // newest load would also wait for every store before it.
+    u32x4 res[2][4];
+    auto load_resid = [&](int mt, u32x4 (&dst)[4]) __attribute__((always_inline)) {
+      if constexpr (EPI == LX2V_EPI_RESIDUAL) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int gm = min(m0 + wm * 128 + mt * 16 + it * 4 + fq, p.M - 1);
+          dst[it] = *reinterpret_cast<const u32x4*>(p.resid + (int64_t)gm * p.ldr + (col_ok ? gn : 0));
+        }
+      }
+    };
+    load_resid(0, res[0]);
+    static_for<0, 8>([&](auto mtc) __attribute__((always_inline)) {
+      constexpr int mt = decltype(mtc)::value;
+      if constexpr (mt + 1 < 8) load_resid(mt + 1, res[(mt + 1) & 1]);
+      static_for<0, 8>([&](auto ntc) __attribute__((always_inline)) {
+        constexpr int nt = decltype(ntc)::value;
+        acc_to_lds<acc_in_agpr(nt, mt)>(waddr[nt], acc[nt][mt]);
+      });
+      // (one wave's LDS instructions execute in order: the reads below see the writes above, and
+      // the next pass's writes come after these reads)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = it * 4 + fq;
+        const int gm = m0 + wm * 128 + mt * 16 + r;
+        const char* row = lds + epi_base + wid * 8192 + r * 512;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(row + (((2 * fr) ^ r) << 4));
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(row + (((2 * fr + 1) ^ r) << 4));
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          v[j] += bv[j];
+          if (EPI == LX2V_EPI_GELU_TANH) v[j] = gelu_tanh(v[j]);
+          if (EPI == LX2V_EPI_RESIDUAL) v[j] *= gv[j];
+        }
+        if (EPI == LX2V_EPI_RESIDUAL) {
+          float y[8];
+          unpack8(res[mt & 1][it], y);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = (float)(__bf16)v[j] + y[j];  // the product is rounded to bf16 before the add, as in the 8-wave kernels
+        }
+        const u32x4 out = pack8(v);
+        if (gm < p.M && col_ok) *reinterpret_cast<u32x4*>(p.C + (int64_t)gm * p.ldc + gn) = out;
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  // ---- prologue: half-tiles 0..3 (K-tiles 0 and 1 of the stream), then the fragments of (0, 0) ----
+  const int my_tiles = (int)blockIdx.x < ntiles ? (ntiles - 1 - (int)blockIdx.x) / grid + 1 : 0;
+  const int64_t total = (int64_t)my_tiles * nk;  // K-tiles in this workgroup's stream
+  if (total == 0) return;
+  static_for<0, 2>([&](auto tc) __attribute__((always_inline)) {
+    constexpr int t = decltype(tc)::value;
+    d_begin();
+    static_for<0, 8>([&](auto qc) __attribute__((always_inline)) { dma_piece_a(dma_base + (2 * t) * TILE_BYTES, qc); });
+    static_for<0, 8>([&](auto qc) __attribute__((always_inline)) { dma_piece_w(dma_base + (2 * t + 1) * TILE_BYTES, qc); });
+    d_advance();
+  });
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    f0.a[i] = read_frag(lds + rd_a[0], i);
+    f0.w[i] = read_frag(lds + TILE_BYTES + rd_w[0], i);
+  }
+
+  // ---- the stream ----
+  int ord = 0, kt = 0;  // output tile ordinal and K-tile of stream position j
+  bool relaxed = false; // the previous K-tile ended in the epilogue of an interior tile (32 stores per wave)
+  int r5 = 0;           // (2 j) % 5: slot of A(j); W(j) r5 + 1, A(j+1) r5 + 2, W(j+1) r5 + 3, free r5 + 4 (all mod 5)
+  auto slot = [&](int k) __attribute__((always_inline)) -> int {  // byte offset of slot (r5 + k) % 5
+    const int s5 = r5 + k;
+    return (s5 >= NSLOT ? s5 - NSLOT : s5) * TILE_BYTES;
+  };
+  for (int64_t j = 0; j < total; ++j) {
+    const int sa = slot(0), sw = slot(1), sa1 = slot(2), sw1 = slot(3), sfree = slot(4);
+    // step 0: reads of (j, 1); DMA of A(j + 2) into the free slot
+    d_begin();
+    if (kt == 0) {
+      kstep(f0, f1, lds + sa + rd_a[1], lds + sw + rd_w[1], dma_base + (uint32_t)sfree, IntC<0>{}, IntC<1>{});
+      if (relaxed) sync_x(IntC<1>{});
+      else sync_x(IntC<0>{});
+    } else {
+      kstep(f0, f1, lds + sa + rd_a[1], lds + sw + rd_w[1], dma_base + (uint32_t)sfree, IntC<0>{}, IntC<0>{});
+      sync_x(IntC<0>{});
+    }
+    // step 1: reads of (j + 1, 0); DMA of W(j + 2) into the slot A(j) has left
+    kstep(f1, f0, lds + sa1 + rd_a[0], lds + sw1 + rd_w[0], dma_base + (uint32_t)sa, IntC<1>{}, IntC<0>{});
+    d_advance();
+    relaxed = false;
+    if (++kt == nk) {
+      int m0, n0;
+      tile_origin(p, ord * grid + (int)blockIdx.x, m0, n0);
+      relaxed = m0 + BM <= p.M && n0 + BN <= p.N;
+      if constexpr (!(W4_ABL & 8)) {
+        epilogue(m0, n0, sw);  // W(j)'s slot is idle until A(j + 3) is staged into it, in the next step 0 ...
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // ... by every wave into every wave's share of the slot: all must have left the epilogue
+      }
+      // Keep the (dead) fragment registers of K-step 1 occupied across the epilogue: handed to its
+      // loads and stores, they would be overwritten by the next K-step's LDS reads while those
+      // memory operations are still counted as pending, and the compiler would protect them with a
+      // vmcnt wait inside the K-loop -- which also waits for the LDS-DMA in flight.
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(f1.a[i]), "+v"(f1.w[i]));
+      kt = 0;
+      ++ord;
+    }
+    r5 += 2;
+    if (r5 >= NSLOT) r5 -= NSLOT;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may still be writing this workgroup's LDS when it ends
+}
+
+}  // namespace
+
+// Launch for p already validated by lx2v_gemm_bf16.  One workgroup per CU (the 160 KiB of LDS allow
+// no second one), never more than there are tiles.
+int lx2v_gemm_launch_w4(lx2v_gemm::GemmParams& p, int epilogue, hipStream_t st) {
+  static int cus_cached[64];
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+    if (cus_cached[dev] == 0) {
+      int v = 0;
+      cus_cached[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    cus = cus_cached[dev];
+  }
+  const int64_t ntiles = (int64_t)p.tiles_m * p.tiles_n;
+  const dim3 grid((unsigned)(ntiles < cus ? ntiles : cus)), block(W4_THREADS);
+  switch (epilogue) {
+    case LX2V_EPI_NONE: hipLaunchKernelGGL(gemm_bf16_w4_kernel<LX2V_EPI_NONE>, grid, block, 0, st, p); break;
+    case LX2V_EPI_GELU_TANH: hipLaunchKernelGGL(gemm_bf16_w4_kernel<LX2V_EPI_GELU_TANH>, grid, block, 0, st, p); break;
+    default: hipLaunchKernelGGL(gemm_bf16_w4_kernel<LX2V_EPI_RESIDUAL>, grid, block, 0, st, p); break;
+  }
+  return LX2V_OK;
+}
