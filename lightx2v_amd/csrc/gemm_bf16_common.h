@@ -30,7 +30,10 @@ using lx2v_gemm::GemmParams;
 
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 32 KiB, same for A and W
-constexpr int GROUP_M = 8;               // tile rasterisation: 8 row-panels share one column sweep
+#ifndef LX2V_GROUP_M
+#define LX2V_GROUP_M 8
+#endif
+constexpr int GROUP_M = LX2V_GROUP_M;    // tile rasterisation: 8 row-panels share one column sweep
 #ifndef GEMM_ABL
 #define GEMM_ABL 0  // timing ablations (wrong results): 1 no load wait, 2 no staging, 4 no barrier, 8 no priority raise (ping-pong), 16 no fragment reads (ping-pong), 32 no epilogue (ping-pong)
 #endif

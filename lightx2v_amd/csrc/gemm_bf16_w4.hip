@@ -36,12 +36,21 @@
 // from the accumulator file, come back as eight consecutive columns per lane, get bias / GELU /
 // gate in fp32 and leave as whole 256-byte row segments of bf16 (residual read the same way, one
 // pass ahead).
+#ifndef LX2V_GROUP_M
+#define LX2V_GROUP_M 4  // measured: 4 row panels per column sweep beat 8 and 16 for this kernel (3.15 vs 3.30 vs 3.66 ms at [75600, 5120] x [5120, 5120])
+#endif
 #include "gemm_bf16_common.h"
 
 namespace {
 
+#ifndef W4_PROBE
+#define W4_PROBE 0  // timing probes of the DMA instruction's issue cost (wrong results)
+#endif
+#ifndef W4_DMA_GROUPS
+#define W4_DMA_GROUPS 2  // the 8 DMA pieces of a half-step go to MFMA groups 0, D, 2 D, ... (1: the first half of the step, 2: spread over all of it)
+#endif
 #ifndef W4_ABL
-#define W4_ABL 0  // timing ablations (wrong results): 1 no LDS-DMA in the loop, 2 no fragment reads, 4 no wait + barrier per K-tile, 8 no epilogue, 16 no MFMAs, 32 wait for the DMA only (no barrier), 64 barrier only (no waits)
+#define W4_ABL 0  // timing ablations (wrong results): 1 no LDS-DMA in the loop, 2 no fragment reads, 4 no wait + barrier per K-tile, 8 no epilogue, 16 no MFMAs, 32 wait for the DMA only (no barrier), 64 barrier only (no waits), 128 no relaxed wait behind an epilogue, 256 every workgroup stages tile (0, 0) (all L2 hits)
 #endif
 constexpr int W4_THREADS = 256;
 constexpr int NSLOT = 5;                      // ring of operand K-tiles
@@ -110,15 +119,26 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_bf16_w4_kernel(const GemmPara
   const int grid = gridDim.x;
   const int nk = p.K / BK;
 
-  // ---- staging: DMA instruction i (0..7) of an operand fills rows 32 i + 8 wid .. + 7 of the tile
-  // image (1 KiB of LDS, lane L the 16 bytes at 16 L: row 8 wid + (L >> 3) + 32 i, position L & 7
-  // holding source chunk (L & 7) ^ ((row >> 1) & 7); the key does not depend on i).
-  const int srow = 8 * wid + (lane >> 3);
-  const int schunk = (lane & 7) ^ ((srow >> 1) & 7);
-  int a_voff = 0;                                                // set with the A descriptor (row stride of the region)
-  const int w_voff = (int)(srow * p.ldw * 2) + schunk * 16;
+  // ---- staging: DMA instruction q (0..7) of wave w fills rows 64 w + 8 q .. + 7 of the tile image
+  // (1 KiB of LDS, lane L the 16 bytes at 16 L: row 64 w + 8 q + (L >> 3), position L & 7 holding
+  // source chunk (L & 7) ^ ((row >> 1) & 7)).  A wave's pieces are 1 KiB apart, so the instruction's
+  // 12-bit offset field (added to the LDS address and to the memory address alike) reaches four of
+  // them from one M0: two M0 writes per half-tile instead of eight.
+  auto piece_voff = [&](int q, int64_t ld) __attribute__((always_inline)) -> int {
+    const int row = 64 * wid + 8 * q + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    return (int)(row * ld * 2) + chunk * 16 - (q & 3) * 1024;  // the offset field adds (q & 3) KiB back
+  };
+  // Per-piece byte offsets of this lane (piece q: 32 q rows further down), kept in registers so that
+  // a piece costs one scalar instruction (M0) and the DMA instruction, nothing else.
+  int a_pv[8], w_pv[8];  // a_pv is set with the A descriptor (row stride of the region)
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    w_pv[q] = piece_voff(q, p.ldw);
+    asm volatile("" : "+v"(w_pv[q]));
+  }
   const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)lds);
-  const uint32_t dma_base = lds_base + 1024 * (uint32_t)wid;
+  const uint32_t dma_base = lds_base + 8192 * (uint32_t)wid;
 
   // DMA cursor: the K-tile staged next, two K-tiles ahead of the one computed.
   int d_ord = 0;                       // ordinal of the cursor's output tile in this workgroup's list
@@ -126,7 +146,6 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_bf16_w4_kernel(const GemmPara
   ACursor d_cur(p);
   int d_region = 0;
   u32x4 a_rs, w_rs;
-  uint32_t a_istep = 0, w_istep = (uint32_t)(32 * p.ldw * 2);
   // Descriptors of the cursor's tile (and A region).  Past the workgroup's last tile they are
   // empty (0 bytes): the DMA instructions of the stream's last two K-tiles then fetch nothing and
   // write zeros into a stage nobody reads, so the loop body needs no "last tiles" variants.
@@ -134,41 +153,54 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_bf16_w4_kernel(const GemmPara
     const int vbid = d_ord * grid + (int)blockIdx.x;
     const bool live = vbid < ntiles;
     int m0 = 0, n0 = 0;
-    if (live) tile_origin(p, vbid, m0, n0);
+    if (live && !(W4_ABL & 256)) tile_origin(p, vbid, m0, n0);
     const int64_t ld = d_region ? p.lda2 : p.lda;
     a_rs = raw_descriptor(p.A + (int64_t)m0 * ld, live ? p.a_bytes - (int64_t)m0 * ld * 2 : 0);
-    a_istep = (uint32_t)(32 * ld * 2);
-    a_voff = (int)(srow * ld * 2) + schunk * 16;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      a_pv[q] = piece_voff(q, ld);
+      asm volatile("" : "+v"(a_pv[q]));
+    }
     w_rs = raw_descriptor(p.W + (int64_t)n0 * p.ldw, live ? p.w_bytes - (int64_t)n0 * p.ldw * 2 : 0);
   };
   d_panel();
 
-  // One DMA instruction: lane L's 16 bytes from rsrc + voff + soff to LDS byte m0 + 16 L.
+  // One DMA instruction: lane L's 16 bytes from rsrc + voff + soff + OFS to LDS byte m0 + OFS + 16 L.
   auto dma_m0 = [&](uint32_t slot_base, auto dstc) __attribute__((always_inline)) {  // M0 = slot base + constant
     asm volatile("s_add_u32 m0, %0, %1" ::"s"(slot_base), "i"(decltype(dstc)::value) : "memory", "scc");
   };
-  auto dma_go = [&](const u32x4& rsrc, int voff, uint32_t soff) __attribute__((always_inline)) {
-    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  auto dma_go = [&](const u32x4& rsrc, int voff, uint32_t soff, auto ofsc) __attribute__((always_inline)) {
+#if W4_PROBE == 1  // M0 only
+    asm volatile("" ::"v"(voff), "s"(rsrc), "s"(soff) : "memory");
+#else
+    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:%3 lds" ::"v"(voff), "s"(rsrc), "s"(soff), "n"(decltype(ofsc)::value) : "memory");
+#endif
   };
-  // The cursor's half-tile (d_half = 0: A, 1: W) in 8 pieces; piece q fills rows 32 q + 8 wid .. + 7
-  // of the slot at LDS byte `slot_base` (which includes this wave's 1 KiB share).
-  int d_half = 0;
+  // The cursor's half-tile in 8 pieces; piece q fills rows 64 wid + 8 q .. + 7 of the slot at LDS
+  // byte `slot_base` (which includes this wave's 8 KiB share).  Pieces 0 and 4 set M0.
   uint32_t d_asoff = 0, d_wsoff = 0;  // scalar byte offsets of the cursor's K-tile
   auto d_begin = [&]() __attribute__((always_inline)) {
     d_asoff = (uint32_t)(d_cur.koff * 2);
     d_wsoff = (uint32_t)d_kt * (BK * 2);
   };
-  auto dma_piece_a = [&](uint32_t slot_base, auto qc) __attribute__((always_inline)) {
+  auto dma_piece_m0 = [&](uint32_t slot_base, auto qc) __attribute__((always_inline)) {
     constexpr int q = decltype(qc)::value;
-    dma_m0(slot_base, IntC<4096 * q>{});
+    if constexpr ((q & 3) == 0) dma_m0(slot_base, IntC<1024 * q>{});
+  };
+  auto dma_piece_go = [&](auto halfc, auto qc) __attribute__((always_inline)) {
+    constexpr int q = decltype(qc)::value;
+    if constexpr (decltype(halfc)::value == 0) dma_go(a_rs, a_pv[q], d_asoff, IntC<1024 * (q & 3)>{});
+    else dma_go(w_rs, w_pv[q], d_wsoff, IntC<1024 * (q & 3)>{});
+  };
+  auto dma_piece_a = [&](uint32_t slot_base, auto qc) __attribute__((always_inline)) {
+    dma_piece_m0(slot_base, qc);
     asm volatile("s_nop 0");
-    dma_go(a_rs, a_voff, d_asoff + (uint32_t)q * a_istep);
+    dma_piece_go(IntC<0>{}, qc);
   };
   auto dma_piece_w = [&](uint32_t slot_base, auto qc) __attribute__((always_inline)) {
-    constexpr int q = decltype(qc)::value;
-    dma_m0(slot_base, IntC<4096 * q>{});
+    dma_piece_m0(slot_base, qc);
     asm volatile("s_nop 0");
-    dma_go(w_rs, w_voff, d_wsoff + (uint32_t)q * w_istep);
+    dma_piece_go(IntC<1>{}, qc);
   };
   auto d_advance = [&]() __attribute__((always_inline)) {  // after the W half of a K-tile
     ++d_kt;
@@ -210,25 +242,33 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_bf16_w4_kernel(const GemmPara
   // (Past the end of the stream the reads return stale bytes that no MFMA uses.)
   auto kstep = [&](Frag& cur, Frag& nxt, const char* na, const char* nw, uint32_t dslot, auto HALFc, auto FIRSTc) __attribute__((always_inline)) {
     constexpr bool FIRST = decltype(FIRSTc)::value != 0;
-    constexpr int HALF = decltype(HALFc)::value;
     static_for<0, 16>([&](auto gc) __attribute__((always_inline)) {
       constexpr int g = decltype(gc)::value, nt = g >> 1, mt0 = 4 * (g & 1);
+      constexpr bool DMA = g % W4_DMA_GROUPS == 0 && g / W4_DMA_GROUPS < 8 && !(W4_ABL & 1);
+      constexpr int q = g / W4_DMA_GROUPS;
+      // One instruction class per MFMA shadow: M0, the DMA instruction, then one fragment read each
+      // (a wave alone on its SIMD issues about one instruction every four cycles, so an MFMA covers three).
       mfma_acc<acc_in_agpr(nt, mt0), FIRST>(acc[nt][mt0], cur.w[nt], cur.a[mt0]);
-      if constexpr ((g & 1) == 0 && !(W4_ABL & 1)) {
-        if constexpr (HALF == 0) dma_piece_a(dslot, IntC<g / 2>{});
-        else dma_piece_w(dslot, IntC<g / 2>{});
-      }
+      if constexpr (DMA) dma_piece_m0(dslot, IntC<q>{});
+      __builtin_amdgcn_sched_barrier(0);
       mfma_acc<acc_in_agpr(nt, mt0 + 1), FIRST>(acc[nt][mt0 + 1], cur.w[nt], cur.a[mt0 + 1]);
+      if constexpr (DMA) dma_piece_go(HALFc, IntC<q>{});
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_acc<acc_in_agpr(nt, mt0 + 2), FIRST>(acc[nt][mt0 + 2], cur.w[nt], cur.a[mt0 + 2]);
       if constexpr (W4_ABL & 2) {
       } else if constexpr (g < 4) {
         nxt.a[2 * g] = read_frag(na, 2 * g);
-        nxt.a[2 * g + 1] = read_frag(na, 2 * g + 1);
       } else if constexpr (g < 8) {
         nxt.w[2 * g - 8] = read_frag(nw, 2 * g - 8);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_acc<acc_in_agpr(nt, mt0 + 3), FIRST>(acc[nt][mt0 + 3], cur.w[nt], cur.a[mt0 + 3]);
+      if constexpr (W4_ABL & 2) {
+      } else if constexpr (g < 4) {
+        nxt.a[2 * g + 1] = read_frag(na, 2 * g + 1);
+      } else if constexpr (g < 8) {
         nxt.w[2 * g - 7] = read_frag(nw, 2 * g - 7);
       }
-      mfma_acc<acc_in_agpr(nt, mt0 + 2), FIRST>(acc[nt][mt0 + 2], cur.w[nt], cur.a[mt0 + 2]);
-      mfma_acc<acc_in_agpr(nt, mt0 + 3), FIRST>(acc[nt][mt0 + 3], cur.w[nt], cur.a[mt0 + 3]);
       __builtin_amdgcn_sched_barrier(0);
     });
   };

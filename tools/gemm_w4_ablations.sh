@@ -9,7 +9,7 @@ if [ "$mode" = build ]; then
   cd lightx2v_amd/csrc
   for m in "$@"; do
     d=../../build/w4abl_$m; mkdir -p $d
-    hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffast-math -fno-finite-math-only -DW4_ABL=$m -x hip -c gemm_bf16_w4.hip -o $d/w4.o || exit 1
+    hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffast-math -fno-finite-math-only -DW4_ABL=${m%%_*} ${W4_EXTRA} -x hip -c gemm_bf16_w4.hip -o $d/w4.o || exit 1
     objs=$(ls ../../build/obj/*.o | grep -v gemm_bf16_w4)
     hipcc --offload-arch=gfx950 -shared -fPIC -o $d/liblx2v_hip.so $objs $d/w4.o && rm $d/w4.o
   done
