@@ -71,7 +71,7 @@ TRAFFIC_FILES = ("r02_attn_traffic.json", "r01_attn_traffic.json")  # newest fir
 
 
 def measured_traffic(S, heads_local):
-    """(bytes, source): HBM-side bytes per self-attention launch from the newest committed PMC
+    """(bytes, source): HBM-side bytes per self-attention call (main + tail launch) from the newest committed PMC
     collection under profiles/ that matches this launch shape (counters cannot be read from inside
     this process: they need their own rocprofv3 pass), or (None, None)."""
     for name in TRAFFIC_FILES:
@@ -81,7 +81,7 @@ def measured_traffic(S, heads_local):
             continue
         w = rec.get("workload", {})
         if w.get("tokens") == S and w.get("heads") == heads_local:
-            return rec.get("traffic_bytes_per_launch"), "profiles/" + name + " (separate rocprofv3 --pmc pass of this workload, not this run)"
+            return rec.get("traffic_bytes_per_call", rec.get("traffic_bytes_per_launch")), "profiles/" + name + " (separate rocprofv3 --pmc pass of this workload, not this run)"
     return None, None
 
 
