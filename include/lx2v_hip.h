@@ -156,6 +156,34 @@ int lx2v_patchify_bf16(float* latents, uint16_t* out, int64_t ldo, int channels,
 int lx2v_unpatchify_f32(const uint16_t* y, int64_t ldy, float* out, int channels, int frames,
                         int height, int width, void* stream);
 
+/* ---- channel planes <-> token rows (patch size (1,1,1): HunyuanVideo-1.5) --------------------
+ * src fp32 [channels, tokens] -> out bf16 [tokens, kpad] (row stride ldo; columns channels..kpad-1
+ * zeroed): a conv3d with kernel = stride = (1,1,1) is then lx2v_gemm_bf16 against
+ * weight.reshape(D, channels) zero-padded to kpad.
+ * Replaces weights.img_in.apply + flatten(2).transpose(1, 2)
+ *                 lightx2v/models/networks/hunyuan_video/infer/pre_infer.py:104-109. */
+int lx2v_channels_to_rows_bf16(const float* src, uint16_t* out, int64_t ldo, int channels,
+                               int64_t tokens, int kpad, void* stream);
+
+/* y bf16 [tokens, channels] (row stride ldy) -> out fp32 [channels, tokens].
+ * Replaces HunyuanVideo15PostInfer.unpatchify (patch (1,1,1)) + .float()
+ *                 lightx2v/models/networks/hunyuan_video/infer/post_infer.py:21-39. */
+int lx2v_rows_to_channels_f32(const uint16_t* y, int64_t ldy, float* out, int channels,
+                              int64_t tokens, void* stream);
+
+/* ---- out bf16 [dim] = sum_l weights[l] x[l, :] / sum_l weights[l] (fp32 accumulation) --------
+ * x bf16 [rows, dim] (row stride ldx), weights fp32 [rows] (a 0/1 mask gives the masked mean).
+ * Replaces (txt * mask).sum(1) / mask.sum(1)
+ *                 lightx2v/models/networks/hunyuan_video/infer/pre_infer.py:141-143. */
+int lx2v_weighted_mean_rows_bf16(const uint16_t* x, int64_t ldx, const float* weights, int rows,
+                                 int dim, uint16_t* out, void* stream);
+
+/* ---- out[r, :] = x[r, :] + vec (bf16, one rounding); out may alias x ------------------------
+ * Replaces txt + cond_type_embedding(...)
+ *                 lightx2v/models/networks/hunyuan_video/infer/pre_infer.py:154-158. */
+int lx2v_add_rowvec_bf16(const uint16_t* x, int64_t ldx, const uint16_t* vec, uint16_t* out,
+                         int64_t ldo, int64_t rows, int dim, void* stream);
+
 /* ---- sinusoidal timestep embedding: out bf16 [dim] = cos(t*w_i) (dim/2) || sin(t*w_i) -------
  * w_i = 10000^(-i/(dim/2)).  `t` is a HOST scalar.
  * Replaces sinusoidal_embedding_1d  lightx2v/models/networks/wan/infer/utils.py:205-215. */

@@ -35,5 +35,13 @@ from .wan_model import (  # noqa: F401,E402
     WanScheduler,
     run_denoise_loop,
 )
+from .hy_model import (  # noqa: F401,E402
+    HunyuanVideo15Model,
+    HunyuanVideo15PostInfer,
+    HunyuanVideo15PreInfer,
+    HunyuanVideo15PreWeights,
+    HunyuanVideo15Scheduler,
+    HunyuanVideo15StepDistillScheduler,
+)
 
 __version__ = "0.1.0"

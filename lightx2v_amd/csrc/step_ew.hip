@@ -75,6 +75,66 @@ __global__ __launch_bounds__(256) void silu_kernel(const uint16_t* __restrict__ 
   }
 }
 
+// src fp32 [C, N] (channel planes) -> rows bf16 [N, ldo], column c; columns C..kpad-1 are zeroed.
+// One thread = one (token, chunk of 8 channels): its loads are coalesced across the wave (adjacent
+// threads = adjacent tokens of one plane), its store is 16 bytes of one row.
+__global__ __launch_bounds__(256) void channels_to_rows_kernel(const float* __restrict__ src, uint16_t* __restrict__ out, int64_t ldo, int C, int64_t N, int kpad) {
+  const int chunks = kpad >> 3;
+  const int64_t total = N * chunks;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t tok = i % N;
+    const int c0 = (int)(i / N) * 8;
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = c0 + j < C ? src[(int64_t)(c0 + j) * N + tok] : 0.f;
+    *reinterpret_cast<u32x4*>(out + tok * ldo + c0) = pack8(f);
+  }
+}
+
+// rows bf16 [N, C] (row stride ldy) -> out fp32 [C, N]; same thread mapping, the other way round.
+__global__ __launch_bounds__(256) void rows_to_channels_kernel(const uint16_t* __restrict__ y, int64_t ldy, float* __restrict__ out, int C, int64_t N) {
+  const int chunks = (C + 7) >> 3;
+  const int64_t total = N * chunks;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t tok = i % N;
+    const int c0 = (int)(i / N) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (c0 + j < C) out[(int64_t)(c0 + j) * N + tok] = __uint_as_float((uint32_t)y[tok * ldy + c0 + j] << 16);
+  }
+}
+
+// out[d] = bf16( sum_l w[l] x[l, d] / sum_l w[l] ), fp32 accumulation in row order.  One thread per
+// column (adjacent threads = adjacent columns: coalesced row reads); the few thousand rows of a
+// text sequence are walked serially.
+__global__ __launch_bounds__(256) void weighted_mean_rows_kernel(const uint16_t* __restrict__ x, int64_t ldx, const float* __restrict__ w, int rows, int dim, uint16_t* __restrict__ out) {
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= dim) return;
+  float acc = 0.f, cnt = 0.f;
+  for (int l = 0; l < rows; ++l) {
+    const float wl = w[l];
+    acc += __uint_as_float((uint32_t)x[(int64_t)l * ldx + d] << 16) * wl;
+    cnt += wl;
+  }
+  out[d] = pack2(acc / cnt, 0.f) & 0xffffu;
+}
+
+// out[r, :] = bf16(x[r, :] + v[:]) (bf16 operands, one rounding), 8 columns per thread
+__global__ __launch_bounds__(256) void add_rowvec_kernel(const uint16_t* __restrict__ x, int64_t ldx, const uint16_t* __restrict__ v, uint16_t* __restrict__ out, int64_t ldo, int64_t rows, int dim) {
+  const int chunks = dim >> 3;
+  const int64_t total = rows * chunks;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / chunks;
+    const int c0 = (int)(i - r * chunks) * 8;
+    float a[8], b[8];
+    unpack8(*reinterpret_cast<const u32x4*>(x + r * ldx + c0), a);
+    unpack8(*reinterpret_cast<const u32x4*>(v + c0), b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] += b[j];
+    *reinterpret_cast<u32x4*>(out + r * ldo + c0) = pack8(a);
+  }
+}
+
 struct LinComb {
   const float* x[4];
   float c[4];
@@ -187,6 +247,45 @@ extern "C" int lx2v_unpatchify_f32(const uint16_t* y, int64_t ldy, float* out, i
   const int64_t n = (int64_t)channels * frames * height * (width / 2);
   hipLaunchKernelGGL(unpatchify_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, y, ldy, out, channels, frames, height, width);
   LX2V_CHECK_LAUNCH("unpatchify");
+  return LX2V_OK;
+}
+
+extern "C" int lx2v_channels_to_rows_bf16(const float* src, uint16_t* out, int64_t ldo, int channels, int64_t tokens, int kpad, void* stream) {
+  LX2V_REQUIRE(src && out, LX2V_EINVAL, "channels_to_rows: null tensor");
+  LX2V_REQUIRE(channels > 0 && tokens > 0 && kpad >= channels && kpad % 8 == 0 && ldo >= kpad && ldo % 8 == 0, LX2V_EINVAL,
+               "channels_to_rows: channels=%d tokens=%lld kpad=%d ldo=%lld (kpad >= channels, kpad and ldo multiples of 8, ldo >= kpad)", channels,
+               (long long)tokens, kpad, (long long)ldo);
+  LX2V_REQUIRE(lx2v_aligned16(out), LX2V_EINVAL, "channels_to_rows: output must be 16-byte aligned");
+  hipLaunchKernelGGL(channels_to_rows_kernel, dim3(ew_blocks(tokens * (kpad / 8))), dim3(256), 0, (hipStream_t)stream, src, out, ldo, channels, tokens, kpad);
+  LX2V_CHECK_LAUNCH("channels_to_rows");
+  return LX2V_OK;
+}
+
+extern "C" int lx2v_rows_to_channels_f32(const uint16_t* y, int64_t ldy, float* out, int channels, int64_t tokens, void* stream) {
+  LX2V_REQUIRE(y && out, LX2V_EINVAL, "rows_to_channels: null tensor");
+  LX2V_REQUIRE(channels > 0 && tokens > 0 && ldy >= channels, LX2V_EINVAL, "rows_to_channels: channels=%d tokens=%lld ldy=%lld", channels, (long long)tokens,
+               (long long)ldy);
+  hipLaunchKernelGGL(rows_to_channels_kernel, dim3(ew_blocks(tokens * ((channels + 7) / 8))), dim3(256), 0, (hipStream_t)stream, y, ldy, out, channels, tokens);
+  LX2V_CHECK_LAUNCH("rows_to_channels");
+  return LX2V_OK;
+}
+
+extern "C" int lx2v_weighted_mean_rows_bf16(const uint16_t* x, int64_t ldx, const float* weights, int rows, int dim, uint16_t* out, void* stream) {
+  LX2V_REQUIRE(x && weights && out, LX2V_EINVAL, "weighted_mean_rows: null tensor");
+  LX2V_REQUIRE(rows > 0 && dim > 0 && ldx >= dim, LX2V_EINVAL, "weighted_mean_rows: rows=%d dim=%d ldx=%lld", rows, dim, (long long)ldx);
+  hipLaunchKernelGGL(weighted_mean_rows_kernel, dim3((dim + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, ldx, weights, rows, dim, out);
+  LX2V_CHECK_LAUNCH("weighted_mean_rows");
+  return LX2V_OK;
+}
+
+extern "C" int lx2v_add_rowvec_bf16(const uint16_t* x, int64_t ldx, const uint16_t* vec, uint16_t* out, int64_t ldo, int64_t rows, int dim, void* stream) {
+  LX2V_REQUIRE(rows == 0 || (x && vec && out), LX2V_EINVAL, "add_rowvec: null tensor");
+  LX2V_REQUIRE(rows >= 0 && dim > 0 && dim % 8 == 0 && ldx >= dim && ldo >= dim && ldx % 8 == 0 && ldo % 8 == 0, LX2V_EINVAL,
+               "add_rowvec: rows=%lld dim=%d ldx=%lld ldo=%lld (dim and strides multiples of 8)", (long long)rows, dim, (long long)ldx, (long long)ldo);
+  LX2V_REQUIRE(lx2v_aligned16(x) && lx2v_aligned16(vec) && lx2v_aligned16(out), LX2V_EINVAL, "add_rowvec: tensors must be 16-byte aligned");
+  if (rows == 0) return LX2V_OK;
+  hipLaunchKernelGGL(add_rowvec_kernel, dim3(ew_blocks(rows * (dim / 8))), dim3(256), 0, (hipStream_t)stream, x, ldx, vec, out, ldo, rows, dim);
+  LX2V_CHECK_LAUNCH("add_rowvec");
   return LX2V_OK;
 }
 

@@ -31,6 +31,10 @@ _SIGNATURES = {
     "lx2v_ulysses_pack_qkv_bf16": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _I, _P],
     "lx2v_patchify_bf16": [_P, _P, _I64, _I, _I, _I, _I, _I, _P],
     "lx2v_unpatchify_f32": [_P, _I64, _P, _I, _I, _I, _I, _P],
+    "lx2v_channels_to_rows_bf16": [_P, _P, _I64, _I, _I64, _I, _P],
+    "lx2v_rows_to_channels_f32": [_P, _I64, _P, _I, _I64, _P],
+    "lx2v_weighted_mean_rows_bf16": [_P, _I64, _P, _I, _I, _P, _P],
+    "lx2v_add_rowvec_bf16": [_P, _I64, _P, _P, _I64, _I64, _I, _P],
     "lx2v_timestep_embedding_bf16": [_F, _I, _P, _P],
     "lx2v_silu_bf16": [_P, _P, _I64, _P],
     "lx2v_lincomb_f32": [_P, _I64, _I, _P, _P, _P],
@@ -378,6 +382,55 @@ def unpatchify(y: torch.Tensor, channels: int, frames: int, height: int, width: 
         raise Lx2vError(f"unpatchify: y {tuple(y.shape)} does not cover a [{channels},{frames},{height},{width}] latent")
     out = torch.empty((channels, frames, height, width), dtype=torch.float32, device=y.device)
     _check(load().lx2v_unpatchify_f32(y.data_ptr(), y.stride(0), out.data_ptr(), channels, frames, height, width, _stream()), "lx2v_unpatchify_f32")
+    return out
+
+
+def channels_to_rows(planes: torch.Tensor, pad_to: int = 0) -> torch.Tensor:
+    """fp32 [C, ...] channel planes -> bf16 [tokens, K] rows (column = channel), zeros in the columns
+    C..K-1 with K = max(C rounded up to 8, pad_to)."""
+    _need_f32_cuda("channels_to_rows.planes", planes)
+    c = planes.shape[0]
+    n = planes.numel() // c
+    k = max((c + 7) // 8 * 8, pad_to)
+    out = torch.empty((n, k), dtype=torch.bfloat16, device=planes.device)
+    _check(load().lx2v_channels_to_rows_bf16(planes.data_ptr(), out.data_ptr(), k, c, n, k, _stream()), "lx2v_channels_to_rows_bf16")
+    return out
+
+
+def rows_to_channels(y: torch.Tensor, channels: int, tokens: int) -> torch.Tensor:
+    """bf16 rows [>= tokens, >= channels] -> fp32 [channels, tokens]."""
+    _need_bf16_cuda("rows_to_channels.y", y)
+    if y.dim() != 2 or y.shape[0] < tokens or y.shape[1] < channels:
+        raise Lx2vError(f"rows_to_channels: y {tuple(y.shape)} does not cover {tokens} tokens x {channels} channels")
+    out = torch.empty((channels, tokens), dtype=torch.float32, device=y.device)
+    _check(load().lx2v_rows_to_channels_f32(y.data_ptr(), y.stride(0), out.data_ptr(), channels, tokens, _stream()), "lx2v_rows_to_channels_f32")
+    return out
+
+
+def weighted_mean_rows(x: torch.Tensor, weights: torch.Tensor) -> torch.Tensor:
+    """bf16 [rows, dim], fp32 weights [rows] -> bf16 [1, dim] = sum_l w_l x_l / sum_l w_l."""
+    _need_bf16_cuda("weighted_mean_rows.x", x)
+    _need_f32_cuda("weighted_mean_rows.weights", weights)
+    if x.dim() != 2 or weights.numel() != x.shape[0]:
+        raise Lx2vError(f"weighted_mean_rows: x {tuple(x.shape)} and weights {tuple(weights.shape)} do not match")
+    out = torch.empty((1, x.shape[1]), dtype=torch.bfloat16, device=x.device)
+    _check(load().lx2v_weighted_mean_rows_bf16(x.data_ptr(), x.stride(0), weights.data_ptr(), x.shape[0], x.shape[1], out.data_ptr(), _stream()),
+           "lx2v_weighted_mean_rows_bf16")
+    return out
+
+
+def add_rowvec(x: torch.Tensor, vec: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16 [rows, dim] + bf16 [dim] -> bf16 [rows, dim] (out may be x)."""
+    _need_bf16_cuda("add_rowvec.x", x)
+    _need_bf16_cuda("add_rowvec.vec", vec)
+    if x.dim() != 2 or vec.numel() != x.shape[1] or not vec.is_contiguous():
+        raise Lx2vError(f"add_rowvec: x {tuple(x.shape)} and vec {tuple(vec.shape)} do not match")
+    if out is None:
+        out = torch.empty_like(x, memory_format=torch.contiguous_format)
+    else:
+        _need_out("add_rowvec.out", out, x.shape, x)
+    _check(load().lx2v_add_rowvec_bf16(x.data_ptr(), x.stride(0), vec.data_ptr(), out.data_ptr(), out.stride(0), x.shape[0], x.shape[1], _stream()),
+           "lx2v_add_rowvec_bf16")
     return out
 
 

@@ -73,6 +73,7 @@ RMS_WEIGHT_REGISTER = Register("rms")
 LN_WEIGHT_REGISTER = Register("ln")
 TENSOR_REGISTER = Register("tensor")
 CONV3D_WEIGHT_REGISTER = Register("conv3d")
+EMBEDDING_WEIGHT_REGISTER = Register("embedding")
 
 _ALL = {
     "MM_WEIGHT_REGISTER": MM_WEIGHT_REGISTER,
@@ -81,6 +82,7 @@ _ALL = {
     "LN_WEIGHT_REGISTER": LN_WEIGHT_REGISTER,
     "TENSOR_REGISTER": TENSOR_REGISTER,
     "CONV3D_WEIGHT_REGISTER": CONV3D_WEIGHT_REGISTER,
+    "EMBEDDING_WEIGHT_REGISTER": EMBEDDING_WEIGHT_REGISTER,
 }
 
 

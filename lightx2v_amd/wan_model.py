@@ -32,14 +32,18 @@ PATCH_SIZE = (1, 2, 2)
 # ------------------------------------------------------------------------------- patch embedding
 @CONV3D_WEIGHT_REGISTER("hip-patch")
 class HipPatchEmbedWeight:
-    """conv3d whose kernel equals its stride (1,2,2) = a GEMM over gathered patches.  Same
-    constructor as the reference's Conv3dWeight (lightx2v/common/ops/conv/conv3d.py:5-14); `apply`
-    takes the latents [C,F,H,W] (fp32) and returns tokens [S, D] (bf16) directly, i.e. the
-    reference's `apply` + `flatten(2).transpose(1,2)` (pre_infer.py:56,63-64)."""
+    """conv3d whose kernel equals its stride -- (1,2,2) for Wan, (1,1,1) for HunyuanVideo-1.5 -- = a
+    GEMM over gathered patches.  Same constructor as the reference's Conv3dWeight
+    (lightx2v/common/ops/conv/conv3d.py:5-14); `apply` takes the latents [C,F,H,W] (fp32) and returns
+    tokens [S, D] (bf16) directly, i.e. the reference's `apply` + `flatten(2).transpose(1,2)`
+    (wan/infer/pre_infer.py:56,63-64; hunyuan_video/infer/pre_infer.py:108-109)."""
+
+    STRIDES = ((1, 2, 2), (1, 1, 1))
 
     def __init__(self, weight_name, bias_name, stride=1, padding=0, dilation=1, groups=1):
-        if tuple(stride) != PATCH_SIZE or padding != 0 or dilation != 1 or groups != 1:
-            raise ValueError("hip-patch implements kernel = stride = (1,2,2), no padding / dilation / groups")
+        stride = (stride,) * 3 if isinstance(stride, int) else tuple(stride)
+        if stride not in self.STRIDES or padding != 0 or dilation != 1 or groups != 1:
+            raise ValueError("hip-patch implements kernel = stride = (1,2,2) or (1,1,1), no padding / dilation / groups")
         self.weight_name, self.bias_name = weight_name, bias_name
         self.stride = stride
         self.config = {}
@@ -52,11 +56,11 @@ class HipPatchEmbedWeight:
 
     def load(self, weight_dict):
         w = weight_dict[self.weight_name]
-        if tuple(w.shape[2:]) != PATCH_SIZE:
-            raise ValueError(f"{self.weight_name}: kernel {tuple(w.shape[2:])}, expected {PATCH_SIZE}")
+        if tuple(w.shape[2:]) != self.stride:
+            raise ValueError(f"{self.weight_name}: kernel {tuple(w.shape[2:])}, expected {self.stride}")
         w2 = w.reshape(w.shape[0], -1).to(torch.bfloat16)
         k = w2.shape[1]
-        kp = (k + 63) // 64 * 64  # the GEMM's K granule: zero columns beyond 4*C (36 channels -> 144 -> 192)
+        kp = (k + 63) // 64 * 64  # the GEMM's K granule: zero columns beyond the patch (Wan 36 channels -> 144 -> 192; HunyuanVideo 65 -> 128)
         self.weight_nk = torch.nn.functional.pad(w2, (0, kp - k)).contiguous()
         self.bias = None if self.bias_name is None else weight_dict[self.bias_name].to(torch.float32).contiguous()
 
@@ -81,6 +85,10 @@ class HipPatchEmbedWeight:
         return destination
 
     def apply(self, latents, round_latents=False):
+        if self.stride == (1, 1, 1):
+            if round_latents:
+                raise ValueError("round_latents belongs to the (1,2,2) patch gather")
+            return hip.gemm(hip.channels_to_rows(latents, pad_to=self.weight_nk.shape[1]), self.weight_nk, self.bias)
         return hip.gemm(hip.patchify(latents, round_latents=round_latents, pad_to=self.weight_nk.shape[1]), self.weight_nk, self.bias)
 
 
