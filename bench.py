@@ -213,12 +213,11 @@ def arithmetic_label(args):
 
 
 def run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu):
-    """HunyuanVideo-1.5 (4-step distilled, no CFG): one step = all double-stream blocks + final layer on
-    synthetic pre-infer outputs (image tokens, text tokens, conditioning vector) + the Euler update.
-    The model's pre-infer (token refiner, byT5 / SigLIP reorder) is outside the built path."""
+    """HunyuanVideo-1.5, 4-step distilled schedule, no CFG: one step = scheduler.step_pre ->
+    HunyuanVideo15Model.infer (pre-infer with the token refiner, all double-stream blocks, final
+    layer, unpatchify) -> scheduler.step_post, on synthetic latents and encoder outputs."""
     import lightx2v_amd as L
     from lightx2v_amd import ulysses
-    from lightx2v_amd.rope_table import build_hunyuan_rope_table
 
     D, H, F, layers = HY_MODELS[args.model]
     if args.layers is not None:
@@ -229,14 +228,18 @@ def run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu):
         seq_p, cfg_p = world, 1  # the distilled model runs without CFG: every rank joins the sequence group
     if H % seq_p != 0:
         raise SystemExit(f"heads_num={H} not divisible by seq_p={seq_p}")
-    seq_idx, seq_group = 0, None
+    seq_group = None
     if world > 1:
-        _, seq_idx, seq_group, _ = ulysses.make_groups(1, seq_p)
-    cfg = {"mm_double_blocks_depth": layers, "heads_num": H, "hidden_size": D, "task": "t2v",
+        _, _, seq_group, _ = ulysses.make_groups(1, seq_p)
+    C, TEXT_DIM, TXT_TOKENS, BYT5_TOKENS, VIS_TOKENS = 32, 3584, 1000, 256, 729
+    cfg = {"mm_double_blocks_depth": layers, "heads_num": H, "hidden_size": D, "task": "t2v", "patch_size": (1, 1, 1), "out_channels": C,
            "dit_quant_scheme": "hip-bf16" if args.linear == "bf16" else "hip-fp8",
            "attn_type": "hip_flash_attn" if args.attn == "bf16" else "hip_fp8_attn",
-           "seq_parallel": seq_p > 1, "seq_p_group": seq_group, "parallel": {"seq_p_size": seq_p, "seq_p_attn_type": "hip_ulysses"}}
-    W = L.HunyuanVideo15TransformerWeights(cfg)
+           "seq_parallel": seq_p > 1, "seq_p_group": seq_group, "parallel": {"seq_p_size": seq_p, "seq_p_attn_type": "hip_ulysses"},
+           "enable_cfg": False, "sample_guide_scale": -1.0, "sample_shift": 5.0, "infer_steps": 4, "denoising_step_list": [1000, 750, 500, 250],
+           "rope_dim_list": [16, 56, 56], "rope_theta": 256.0, "run_device": str(dev)}
+    model = L.HunyuanVideo15Model(cfg)
+    W = model.transformer_weights
     g = torch.Generator(device=dev).manual_seed(1234)  # same seed on every rank: weights are replicated
 
     def rn(*shape, std=1.0, dtype=torch.bfloat16):
@@ -255,31 +258,48 @@ def run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu):
         W.double_blocks[i].img_branch.fused_qkv()
         W.double_blocks[i].txt_branch.fused_qkv()
     W.final_layer.load({"final_layer.adaLN_modulation.1.weight": rn(2 * D, D, std=1.0 / math.sqrt(D)), "final_layer.adaLN_modulation.1.bias": rn(2 * D, std=0.02, dtype=torch.float32),
-                        "final_layer.linear.weight": rn(32, D, std=0.02), "final_layer.linear.bias": rn(32, std=0.02, dtype=torch.float32)})
-    inf = L.HunyuanVideo15TransformerInfer(cfg)
-    S_pad = S + (seq_p - S % seq_p) % seq_p
-    sl = S_pad // seq_p
-    table = torch.zeros(S_pad, D // H)
-    table[:S] = build_hunyuan_rope_table(grid, D // H)
-    inf.scheduler.cos_sin = table[seq_idx * sl:(seq_idx + 1) * sl].contiguous().to(dev)
+                        "final_layer.linear.weight": rn(C, D, std=0.02), "final_layer.linear.bias": rn(C, std=0.02, dtype=torch.float32)})
+    pre = {"img_in.proj.weight": rn(D, 2 * C + 1, 1, 1, 1, std=0.05), "img_in.proj.bias": rn(D, std=0.02, dtype=torch.float32),
+           "cond_type_embedding.weight": rn(3, D, std=0.1)}
+    lin = {"time_in.mlp.0": (D, 256), "time_in.mlp.2": (D, D), "txt_in.t_embedder.mlp.0": (D, 256), "txt_in.t_embedder.mlp.2": (D, D),
+           "txt_in.c_embedder.linear_1": (D, TEXT_DIM), "txt_in.c_embedder.linear_2": (D, D), "txt_in.input_embedder": (D, TEXT_DIM)}
+    for i in range(2):
+        rb = f"txt_in.individual_token_refiner.blocks.{i}."
+        lin.update({rb + "self_attn_qkv": (3 * D, D), rb + "self_attn_proj": (D, D), rb + "mlp.fc1": (4 * D, D), rb + "mlp.fc2": (D, 4 * D),
+                    rb + "adaLN_modulation.1": (2 * D, D)})
+        for n in ("norm1", "norm2"):
+            pre[rb + n + ".weight"], pre[rb + n + ".bias"] = torch.ones(D, device=dev), torch.zeros(D, device=dev)
+    for name, (o, k) in lin.items():
+        pre[name + ".weight"], pre[name + ".bias"] = rn(o, k, std=0.02), rn(o, std=0.02, dtype=torch.float32)
+    model.pre_weight.load(pre)
+    sch = L.HunyuanVideo15StepDistillScheduler(cfg)
+    model.set_scheduler(sch)
+
     g2 = torch.Generator(device=dev).manual_seed(99)
-    img_tokens = torch.zeros(1, S_pad, D, device=dev, dtype=torch.bfloat16)
-    img_tokens[:, :S] = torch.randn(1, S, D, generator=g2, device=dev, dtype=torch.float32).to(torch.bfloat16)
-    img_local = img_tokens[:, seq_idx * sl:(seq_idx + 1) * sl].contiguous()
-    txt = torch.randn(1, HY_TEXT_LEN, D, generator=g2, device=dev, dtype=torch.float32).to(torch.bfloat16)
-    vec = torch.nn.functional.silu(0.5 * torch.randn(1, D, generator=g2, device=dev, dtype=torch.float32)).to(torch.bfloat16)
-    latents = torch.randn(sl, 32, generator=g2, device=dev, dtype=torch.float32)  # token-major view of this rank's latent rows
-    sigmas = torch.linspace(1.0, 0.0, 5).tolist()
+
+    def mask(n, valid):
+        m = torch.zeros(1, n, dtype=torch.int64, device=dev)
+        m[:, :valid] = 1
+        return m
+
+    inputs = {"text_encoder_output": {"context": [rn(1, TXT_TOKENS, TEXT_DIM), mask(TXT_TOKENS, HY_TEXT_LEN)], "context_null": [rn(1, TXT_TOKENS, TEXT_DIM), mask(TXT_TOKENS, 1)],
+                                      "byt5_features": rn(1, BYT5_TOKENS, D), "byt5_masks": mask(BYT5_TOKENS, 0)},
+              "image_encoder_output": {"siglip_output": torch.zeros(1, VIS_TOKENS, D, device=dev, dtype=torch.bfloat16), "siglip_mask": mask(VIS_TOKENS, 0).to(torch.bfloat16),
+                                       "cond_latents": None}}
+    latents0 = torch.randn(1, C, *grid, generator=g2, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    sch.prepare(0, (C, *grid), image_encoder_output=inputs["image_encoder_output"], latents=latents0)
     timers = [AttnTimer(W.double_blocks[i].self_attention) for i in range(layers)]
     step_no = [0]
 
     def step():
-        i = step_no[0] % 4
+        i = step_no[0] % sch.infer_steps
         step_no[0] += 1
-        io = L.HunyuanVideo15InferModuleOutput(img=img_local, txt=txt, vec=vec, grid_sizes=grid)
-        pred = inf.infer(W, io)[0].float()  # [sl, 32]
-        latents.add_(pred, alpha=sigmas[i + 1] - sigmas[i])  # Euler update of the flow-matching sampler
-        return latents
+        if i == 0:
+            sch.latents = latents0.clone()
+        sch.step_pre(step_index=i)
+        model.infer(inputs)
+        sch.step_post()
+        return sch.latents
 
     def fence():
         torch.cuda.synchronize()
@@ -291,6 +311,8 @@ def run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu):
         step()
     for t in timers:
         t.enabled = True
+    if world > 1:
+        ulysses.COMM_TIMER.enable()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -301,7 +323,8 @@ def run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu):
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    assert torch.isfinite(out).all()
+    assert torch.isfinite(out.float()).all()
+    exposed_ms = ulysses.COMM_TIMER.total_ms() / args.steps if world > 1 else 0.0
     s_per_step = elapsed / args.steps
     n_launches = sum(len(t.events) for t in timers)
     attn_ms = sum(t.total_ms() for t in timers) / max(1, n_launches)
@@ -315,11 +338,12 @@ def run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu):
         "value": s_per_step, "unit": "s/denoise-step", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": s_per_step * 1e3, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
         "dtype": arithmetic_label(args)[0],
-        "data": "synthetic image/text tokens and conditioning vector, random-init weights of the named architecture"
+        "data": "synthetic latents, text / glyph / image-encoder features and masks, random-init weights of the named architecture"
                 + ("" if (backend == "nccl" and not share_gpu) else f" [REHEARSAL: backend={backend} share_gpu={share_gpu}, not a measurement]"),
-        "config": {"workload": f"{args.model} {args.res} x{frames}f: {S} image + {HY_TEXT_LEN} text tokens, {layers} double-stream blocks + final layer + Euler update, no CFG (distilled schedule); pre-infer not included",
+        "config": {"workload": f"{args.model} {args.res} x{frames}f: {S} image + {HY_TEXT_LEN} text tokens, full denoise step (pre-infer with token refiner, {layers} double-stream blocks + final layer, unpatchify, distilled-schedule update), no CFG",
                    "parallelism": f"seq_p{seq_p} (ulysses)", "tokens": S, "dim": D, "heads": H, "ffn_dim": F, "layers": layers},
         "step_tflops": step_flops / 1e12, "achieved_tflops_per_gpu": step_flops / s_per_step / 1e12 / world,
+        "exposed_comm_ms_per_step": exposed_ms, "ulysses_chunks": int(os.environ.get("LX2V_ULYSSES_CHUNKS", "2")),
         "roofline": {"kernel": ("attn_fwd_x16_kernel" if args.attn == "bf16" else "attn_fwd_fp8_kernel<false> + quantisation pre-pass") + " (joint image+text attention)",
                      "bound": "mfma", "achieved": achieved, "peak": attn_peak(args),
                      "unit": "TFLOP/s", "frac": achieved / attn_peak(args), "traffic": None,

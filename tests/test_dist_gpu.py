@@ -258,3 +258,47 @@ def test_model_infer_with_cfg_and_sequence_parallel_groups(cuda, tmp_path, cfg_p
             assert cos(res[r]["preds"][i], gold) >= 0.999, (i, r, cos(res[r]["preds"][i], gold))
             assert torch.equal(res[r]["preds"][i], res[0]["preds"][i]), (i, r)   # all ranks hold the combined prediction
     assert cos(res[0]["latents"], torch.from_numpy(np.asarray(rec["latents_2"]))) >= 0.9995
+
+
+def _hy_model_worker(rank, world, port, out_dir, name, cfg_p, seq_p):
+    dev = _init(rank, world, port)
+    import lightx2v_amd as L
+    from lightx2v_amd import ulysses
+    from tests.test_hy_step_gpu import _model, _to_cuda
+    from tests.test_hy_step_oracle import hy_step_case
+
+    rec, meta, pre_w, blocks, fw, inputs = hy_step_case(name)
+    _, _, seq_group, cfg_group = ulysses.make_groups(cfg_p, seq_p)
+    m, sch = _model(meta, pre_w, blocks, fw, dev, cfg_parallel=cfg_p > 1, cfg_p_group=cfg_group, seq_parallel=seq_p > 1, seq_p_group=seq_group,
+                    parallel={"seq_p_size": seq_p, "cfg_p_size": cfg_p, "seq_p_attn_type": "hip_ulysses"})
+    dev_inputs = _to_cuda(inputs, dev)
+    sch.prepare(meta["seed"], meta["latent_shape"], image_encoder_output=dev_inputs["image_encoder_output"], latents=torch.from_numpy(rec["latents0"]))
+    preds = []
+    for i in range(2):
+        sch.step_pre(i)
+        m.infer(dev_inputs)
+        preds.append(sch.noise_pred.float().cpu())
+        sch.step_post()
+    torch.save({"preds": preds, "latents": sch.latents.float().cpu()}, os.path.join(out_dir, f"h{rank}.pt"))
+    _finish()
+
+
+@pytest.mark.parametrize("name,cfg_p,seq_p", [("hy_step_distill_d256", 1, 2), ("hy_step_cfg_i2v_d256", 2, 1), ("hy_step_cfg_i2v_d256", 2, 2)])
+def test_hunyuan_model_infer_with_cfg_and_sequence_parallel_groups(cuda, tmp_path, name, cfg_p, seq_p):
+    """`HunyuanVideo15Model.infer` on a (cfg_p, seq_p) grid: the image tokens are chunked over the
+    sequence group while every rank keeps the whole text, Ulysses runs inside every double-stream
+    block, the final layer's rows are gathered, the two CFG branches are gathered and combined."""
+    import numpy as np
+    from tests.test_hy_step_oracle import hy_step_case
+    from tests.util import cos
+
+    world = cfg_p * seq_p
+    _spawn(_hy_model_worker, lambda port: (world, port, str(tmp_path), name, cfg_p, seq_p), world)
+    rec, meta, *_ = hy_step_case(name)
+    res = [torch.load(os.path.join(str(tmp_path), f"h{r}.pt")) for r in range(world)]
+    for i in range(2):
+        gold = torch.from_numpy(np.asarray(rec[f"noise_pred_{i}"]))
+        for r in range(world):
+            assert cos(res[r]["preds"][i], gold) >= 0.999, (i, r, cos(res[r]["preds"][i], gold))
+            assert torch.equal(res[r]["preds"][i], res[0]["preds"][i]), (i, r)
+    assert cos(res[0]["latents"], torch.from_numpy(np.asarray(rec["latents_2"]))) >= 0.9995
