@@ -36,6 +36,9 @@ namespace {
 #ifndef X16_ABL
 #define X16_ABL 0  // timing ablations (results are wrong with any bit set): 1 softmax VALU, 2 fragment reads, 4 staging, 8 barrier, 16 overflow check, 32 K fragment reads, 64 V fragment reads, 128 exps (moves instead), 256 softmax VALU other than exps, 512 K staging, 1024 V staging
 #endif
+#ifndef X16_LAG
+#define X16_LAG 0  // test builds only: s_sleep argument for one wave per tile, directly behind the tile barrier
+#endif
 constexpr int X16_THREADS = 256;
 constexpr int RING = 4;                        // tiles per LDS ring
 constexpr int K_RING = 0;                      // LDS byte offset of K slot 0
@@ -372,14 +375,21 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
           }
         }
         // Tile barrier: K(t+1) and V(t) (issued three tiles ago) have landed; after the barrier that
-        // holds for every wave.  This wave's last reads of K(t) and V(t-1) were issued before this
-        // point but are not waited for: an issued LDS read completes within ~10^2 cycles whatever
-        // its wave does next, while the first DMA into those slots is issued 8 steps (>= 512 cycles)
-        // after the barrier and lands an L2 latency later still.
+        // holds for every wave.  Slot reuse is safe in program order, not by timing: every read of
+        // K(t) and V(t-1) -- the slots that DMA instructions issued after this barrier overwrite --
+        // precedes the barrier in each wave's instruction stream (the last ones are the fragment
+        // requests of steps 10 and 11), so when any wave issues such a DMA, all four waves' reads
+        // of the slot are already in the CU's LDS queue, which serves its requests in order; the
+        // DMA's data arrives there nine steps and a memory round trip later.  They are not waited
+        // for here (their consumers wait, within four steps).  X16_LAG holds one wave back behind
+        // the barrier to check the first half of that argument (tests/test_attn_fullsize_gpu.py).
         if constexpr (qb == NQB - 1 && PAR == 0 && s == 11 && !(X16_ABL & 8)) {
           asm volatile("" ::: "memory");
           __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * DMA_PER_GROUP) & 15) | (((2 * DMA_PER_GROUP) >> 4) << 14));  // vmcnt(16)
           __builtin_amdgcn_s_barrier();
+#if X16_LAG
+          if (wid == (t & 3)) __builtin_amdgcn_s_sleep(X16_LAG);  // 64 X16_LAG cycles behind the others, a different wave every tile
+#endif
           asm volatile("" ::: "memory");
         }
         __builtin_amdgcn_sched_barrier(0);

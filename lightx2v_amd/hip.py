@@ -15,6 +15,7 @@ from typing import Optional
 import torch
 
 _LIB_NAME = "liblx2v_hip.so"
+ABI_VERSION = 2  # include/lx2v_hip.h: lx2v_abi_version()
 _lib: Optional[ctypes.CDLL] = None
 
 EPI_NONE, EPI_GELU_TANH, EPI_RESIDUAL = 0, 1, 2

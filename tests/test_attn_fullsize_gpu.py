@@ -78,3 +78,34 @@ def test_w4_kernel_at_full_length(case, options):
     out = hip.attn_fwd(q[:, :2], k[:, :2], v[:, :2])   # 2 heads: 592 workgroups of 256 rows
     got = out[rows.to(out.device)].float().cpu()
     assert cos(got, ref[:, :2 * D]) >= 0.9999
+
+
+def test_a_wave_held_back_behind_the_tile_barrier_changes_nothing(case, options):
+    """The kernel reuses a K / V ring slot for LDS-DMA one barrier after its last reads were issued,
+    without waiting for those reads.  That is safe when every read of the slot precedes the barrier
+    in program order; the test build `build/x16_lag/liblx2v_hip.so` (make -C lightx2v_amd/csrc
+    lagtest) makes one wave per tile sleep 512 cycles directly behind the barrier -- five steps of
+    the others' progress, enough for their first DMA into the slot to be issued -- so a read of the
+    slot that came after the barrier would now see overwritten data.  Same shape, same launch plan:
+    the output must be bit-identical to the product library's."""
+    import ctypes
+    import os
+
+    from lightx2v_amd.hip import _SIGNATURES
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "x16_lag", "liblx2v_hip.so")
+    if not os.path.exists(path):
+        pytest.skip("build/x16_lag/liblx2v_hip.so not built (make -C lightx2v_amd/csrc lagtest)")
+    q, k, v, rows, ref = case
+    options(attn_kernel=16, attn_qb=5, attn_tail=1)
+    want = hip.attn_fwd(q, k, v)
+    lag = ctypes.CDLL(path)
+    lag.lx2v_attn_fwd_bf16.argtypes = _SIGNATURES["lx2v_attn_fwd_bf16"]
+    lag.lx2v_attn_fwd_bf16.restype = ctypes.c_int
+    lag.lx2v_last_error.restype = ctypes.c_char_p
+    got = torch.empty_like(want)
+    st = lag.lx2v_attn_fwd_bf16(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), got.data_ptr(), got.stride(0),
+                                S, S, H, D, float(D ** -0.5), None, torch.cuda.current_stream().cuda_stream)
+    assert st == 0, lag.lx2v_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
