@@ -83,6 +83,11 @@ int lx2v_gate_residual_bf16(uint16_t* x, int64_t ldx, const uint16_t* y, int64_t
  * Replaces torch.nn.functional.gelu(approximate="tanh")  transformer_infer.py:305. */
 int lx2v_gelu_tanh_bf16(const uint16_t* x, uint16_t* out, int64_t n, void* stream);
 
+/* ---- exact (erf) GELU, bf16, out may alias x; n % 8 == 0 -----------------------------------
+ * Replaces torch.nn.functional.gelu(approximate="none") of the CLIP image-token MLP
+ *                 lightx2v/models/networks/wan/infer/pre_infer.py:106. */
+int lx2v_gelu_erf_bf16(const uint16_t* x, uint16_t* out, int64_t n, void* stream);
+
 /* ---- Linear: C = epilogue(A @ W^T + bias) on MFMA ------------------------------------------
  * A [M,K] (row stride lda), W [N,K] (the checkpoint's [out,in] layout, row stride ldw),
  * bias fp32 [N] or NULL, C [M,N] (row stride ldc), fp32 accumulation.

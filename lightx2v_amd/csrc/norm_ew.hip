@@ -198,6 +198,17 @@ __global__ __launch_bounds__(256) void gelu_tanh_kernel(const uint16_t* __restri
   }
 }
 
+// exact GELU: x Phi(x) = 0.5 x (1 + erf(x / sqrt 2))
+__global__ __launch_bounds__(256) void gelu_erf_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ out, int64_t nchunks) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (int64_t)gridDim.x * blockDim.x) {
+    float a[8];
+    unpack8(*reinterpret_cast<const u32x4*>(x + i * 8), a);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = 0.5f * a[j] * (1.0f + erff(a[j] * 0.70710678118654752f));
+    *reinterpret_cast<u32x4*>(out + i * 8) = pack8(a);
+  }
+}
+
 // out[dst][row][which][c] = src_which[row][dst*seg + c], seg = dim/world
 __global__ __launch_bounds__(256) void ulysses_pack_kernel(const uint16_t* __restrict__ q, int64_t ldq,
                                                            const uint16_t* __restrict__ k, int64_t ldk,
@@ -312,6 +323,16 @@ extern "C" int lx2v_gelu_tanh_bf16(const uint16_t* x, uint16_t* out, int64_t n, 
   if (n == 0) return LX2V_OK;
   hipLaunchKernelGGL(gelu_tanh_kernel, dim3(ew_grid(n >> 3)), dim3(256), 0, (hipStream_t)stream, x, out, n >> 3);
   LX2V_CHECK_LAUNCH("gelu_tanh");
+  return LX2V_OK;
+}
+
+extern "C" int lx2v_gelu_erf_bf16(const uint16_t* x, uint16_t* out, int64_t n, void* stream) {
+  LX2V_REQUIRE(n == 0 || (x && out), LX2V_EINVAL, "gelu_erf: null tensor");
+  LX2V_REQUIRE(n >= 0 && n % 8 == 0, LX2V_EINVAL, "gelu_erf: n=%lld must be a multiple of 8", (long long)n);
+  LX2V_REQUIRE(lx2v_aligned16(x) && lx2v_aligned16(out), LX2V_EINVAL, "gelu_erf: tensors must be 16-byte aligned");
+  if (n == 0) return LX2V_OK;
+  hipLaunchKernelGGL(gelu_erf_kernel, dim3(ew_grid(n >> 3)), dim3(256), 0, (hipStream_t)stream, x, out, n >> 3);
+  LX2V_CHECK_LAUNCH("gelu_erf");
   return LX2V_OK;
 }
 

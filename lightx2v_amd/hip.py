@@ -27,6 +27,7 @@ _SIGNATURES = {
     "lx2v_rmsnorm_rope_bf16": [_P, _I64, _P, _I, _P, _I, _P, _I64, _I64, _I, _F, _P],
     "lx2v_gate_residual_bf16": [_P, _I64, _P, _I64, _P, _I64, _I, _P],
     "lx2v_gelu_tanh_bf16": [_P, _P, _I64, _P],
+    "lx2v_gelu_erf_bf16": [_P, _P, _I64, _P],
     "lx2v_gemm_bf16": [_P, _I64, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _I64, _I, _P, _I64, _P, _P],
     "lx2v_attn_fwd_bf16": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I, _I, _F, _P, _P],
     "lx2v_ulysses_pack_qkv_bf16": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _I, _P],
@@ -202,6 +203,16 @@ def gate_residual_(x: torch.Tensor, y: torch.Tensor, gate=None) -> torch.Tensor:
     st = load().lx2v_gate_residual_bf16(x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), _ptr(g), rows, dim, _stream())
     _check(st, "lx2v_gate_residual_bf16")
     return x
+
+
+def gelu_erf(x: torch.Tensor) -> torch.Tensor:
+    """Exact GELU (bf16 in / out)."""
+    _need_bf16_cuda("gelu_erf.x", x)
+    if not x.is_contiguous():
+        raise Lx2vError("gelu_erf: input must be contiguous")
+    out = torch.empty_like(x)
+    _check(load().lx2v_gelu_erf_bf16(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "lx2v_gelu_erf_bf16")
+    return out
 
 
 def gelu_tanh(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

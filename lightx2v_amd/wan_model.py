@@ -21,7 +21,7 @@ import torch
 import torch.distributed as dist
 
 from . import comm, hip
-from .registry_factory import CONV3D_WEIGHT_REGISTER, MM_WEIGHT_REGISTER
+from .registry_factory import CONV3D_WEIGHT_REGISTER, LN_WEIGHT_REGISTER, MM_WEIGHT_REGISTER
 from .rope_table import build_rope_table, shard_rope_table
 from .wan_block import WanPreInferModuleOutput, WanTransformerInfer, WanTransformerWeights, with_defaults
 from .weight_module import WeightModule
@@ -96,9 +96,8 @@ class WanPreWeights(WeightModule):
     def __init__(self, config):
         super().__init__()
         config = with_defaults(config)
-        if config["task"] != "t2v" and not (config["task"] == "i2v" and not config.get("use_image_encoder", True)):
-            raise NotImplementedError(f"task={config['task']!r} with a CLIP image encoder: that pre-infer branch (img_emb.proj.*) is not built; "
-                                      "t2v and i2v with use_image_encoder=false (Wan2.2 two-expert) are")
+        if config["task"] not in ("t2v", "i2v"):
+            raise NotImplementedError(f"task={config['task']!r}: t2v and i2v (with or without a CLIP image encoder) are built; flf2v / animate / s2v are not")
         self.in_dim, self.dim, self.patch_size, self.config = config["in_dim"], config["dim"], PATCH_SIZE, config
         mm = MM_WEIGHT_REGISTER[config["dit_quant_scheme"]]
         self.add_module("patch_embedding", CONV3D_WEIGHT_REGISTER["hip-patch"]("patch_embedding.weight", "patch_embedding.bias", stride=PATCH_SIZE))
@@ -107,6 +106,13 @@ class WanPreWeights(WeightModule):
         self.add_module("time_embedding_0", mm("time_embedding.0.weight", "time_embedding.0.bias"))
         self.add_module("time_embedding_2", mm("time_embedding.2.weight", "time_embedding.2.bias"))
         self.add_module("time_projection_1", mm("time_projection.1.weight", "time_projection.1.bias"))
+        if config["task"] == "i2v" and config.get("use_image_encoder", True):
+            # CLIP image tokens -> LN, Linear, GELU, Linear, LN (pre_weights.py:43-59); never quantised there
+            ln, bf = LN_WEIGHT_REGISTER["hip"], MM_WEIGHT_REGISTER["hip-bf16"]
+            self.add_module("proj_0", ln("img_emb.proj.0.weight", "img_emb.proj.0.bias"))
+            self.add_module("proj_1", bf("img_emb.proj.1.weight", "img_emb.proj.1.bias"))
+            self.add_module("proj_3", bf("img_emb.proj.3.weight", "img_emb.proj.3.bias"))
+            self.add_module("proj_4", ln("img_emb.proj.4.weight", "img_emb.proj.4.bias"))
 
 
 class GridOutput:
@@ -160,6 +166,12 @@ class WanPreInfer:
             ctx = ctx.to(torch.bfloat16)
         out = weights.text_embedding_0.apply_gelu(ctx.contiguous())
         ctx = weights.text_embedding_2.apply(out)
+        if self.task == "i2v" and self.config.get("use_image_encoder", True):
+            # 257 CLIP tokens through img_emb, in front of the text tokens (pre_infer.py:99-113)
+            clip_fea = inputs["image_encoder_output"]["clip_encoder_out"]
+            clip_fea = (clip_fea[0] if clip_fea.dim() == 3 else clip_fea).to(torch.bfloat16).contiguous()
+            h = hip.gelu_erf(weights.proj_1.apply(weights.proj_0.apply(clip_fea)))
+            ctx = torch.cat([weights.proj_4.apply(weights.proj_3.apply(h)), ctx], dim=0)
         grid_sizes = GridOutput(tensor=torch.tensor([list(grid)], dtype=torch.int32, device=x.device), tuple=grid)
         return WanPreInferModuleOutput(embed=embed, grid_sizes=grid_sizes, x=x, embed0=embed0.squeeze(0), context=ctx, adapter_args={"motion_vec": None})
 

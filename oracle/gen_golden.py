@@ -77,7 +77,7 @@ def _ref_block_objects(cfg, w, block_index=0):
     from lightx2v.models.networks.wan.infer.transformer_infer import WanTransformerInfer
     from lightx2v.models.networks.wan.weights.transformer_weights import WanTransformerAttentionBlock
 
-    blk = WanTransformerAttentionBlock(block_index, "t2v", "Default", cfg)
+    blk = WanTransformerAttentionBlock(block_index, cfg.get("task", "t2v"), "Default", cfg)
     sa, ca, ff = blk.compute_phases
     p = f"blocks.{block_index}."
 
@@ -96,6 +96,10 @@ def _ref_block_objects(cfg, w, block_index=0):
     ca.norm3.bias = w[p + "norm3.bias"]
     ca.cross_attn_norm_q.weight = w[p + "cross_attn.norm_q.weight"]
     ca.cross_attn_norm_k.weight = w[p + "cross_attn.norm_k.weight"]
+    if hasattr(ca, "cross_attn_k_img"):  # i2v with a CLIP image encoder
+        set_mm(ca.cross_attn_k_img, "cross_attn.k_img")
+        set_mm(ca.cross_attn_v_img, "cross_attn.v_img")
+        ca.cross_attn_norm_k_img.weight = w[p + "cross_attn.norm_k_img.weight"]
     ff.norm2.weight = ff.norm2.bias = None
     set_mm(ff.ffn_0, "ffn.0")
     set_mm(ff.ffn_2, "ffn.2")

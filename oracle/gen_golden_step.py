@@ -51,6 +51,11 @@ def reference_objects(cfg, model, layers):
         mm = getattr(pre_w, attr)
         mm.weight = model[key + ".weight"].t()
         mm.bias = model[key + ".bias"]
+    if hasattr(pre_w, "proj_0"):  # i2v with a CLIP image encoder: img_emb.proj.{0,1,3,4}
+        for attr, key in (("proj_0", "img_emb.proj.0"), ("proj_4", "img_emb.proj.4")):
+            getattr(pre_w, attr).weight, getattr(pre_w, attr).bias = model[key + ".weight"], model[key + ".bias"]
+        for attr, key in (("proj_1", "img_emb.proj.1"), ("proj_3", "img_emb.proj.3")):
+            getattr(pre_w, attr).weight, getattr(pre_w, attr).bias = model[key + ".weight"].t(), model[key + ".bias"]
     blocks = []
     infer = None
     for i in range(layers):
@@ -213,14 +218,83 @@ def run_two_expert_case(name, latent_shape, dim, heads, ffn, layers, text_len, t
     print(f"{name}: {steps} steps, experts {picks}, worst |restatement - reference| = {worst:.3e}")
 
 
+def run_clip_i2v_case(name, latent_shape, dim, heads, ffn, layers, text_len, text_dim, clip_dim, steps, shift, guide, seed, out_dir):
+    """Wan2.1 i2v with a CLIP image encoder: in_dim = 16 + 20 (latents + mask / VAE conditioning), 257 image
+    tokens through img_emb in front of the text context, k_img / v_img / norm_k_img and a second
+    cross-attention in every block.  The reference's WanPreInfer (task i2v), blocks, head,
+    WanPostInfer and WanScheduler run a CFG loop; wan_step_ref must reproduce every step."""
+    cfg = {
+        "dim": dim, "num_heads": heads, "num_layers": layers, "ffn_dim": ffn, "in_dim": 36, "out_dim": 16, "freq_dim": 256, "text_len": text_len,
+        "task": "i2v", "model_cls": "wan2.1", "use_image_encoder": True, "run_device": "cpu", "cpu_offload": False, "seq_parallel": False,
+        "cfg_parallel": False, "self_attn_1_type": "torch_sdpa", "cross_attn_1_type": "torch_sdpa", "cross_attn_2_type": "torch_sdpa",
+        "modulate_type": "torch", "rope_type": "torch", "infer_steps": steps, "target_video_length": 4 * (latent_shape[1] - 1) + 1,
+        "sample_shift": shift, "sample_guide_scale": guide, "enable_cfg": True, "feature_caching": "NoCaching",
+    }
+    model = build_model(dim, ffn, layers, text_dim, seed, in_dim=36)
+    for i in range(layers):
+        model.update(R.make_image_branch_weights(dim, seed=seed, block_index=i))
+    model.update(T.make_img_emb_weights(dim, clip_dim, seed=seed))
+    pre_w, blocks, head, pre, infer, post, sch = reference_objects(cfg, model, layers)
+    g = torch.Generator().manual_seed(seed * 7919 + 41)
+    context = torch.randn(text_len, text_dim, generator=g)
+    context_null = torch.randn(text_len, text_dim, generator=g)
+    y = torch.randn(20, *latent_shape[1:], generator=g)
+    clip_fea = torch.randn(R.IMAGE_TOKENS, clip_dim, generator=g)
+    inputs = {"text_encoder_output": {"context": context.unsqueeze(0), "context_null": context_null.unsqueeze(0)},
+              "image_encoder_output": {"vae_encoder_out": y, "clip_encoder_out": clip_fea}}
+    sch.prepare(seed, latent_shape)
+    latents0 = sch.latents.clone()
+    infer.cos_sin = sch.cos_sin
+    store = {"latents0": latents0.numpy(), "context": context.numpy(), "context_null": context_null.numpy(), "y": y.numpy(), "clip_fea": clip_fea.numpy()}
+    mine = T.UniPC(steps, shift)
+    lat = latents0
+    worst = 0.0
+    for i in range(steps):
+        sch.step_pre(step_index=i)
+        preds = []
+        for cond in (True, False):
+            sch.infer_condition = cond
+            out = pre.infer(pre_w, inputs)
+            if i == 0 and cond:
+                store["pre_context"] = out.context.numpy().copy()
+                ctx_mine = T.pre_infer(model, lat, sch.timestep_input, context, y=y, clip_fea=clip_fea)[3]
+                assert (ctx_mine - out.context).abs().max().item() < 2e-5
+            x = out.x
+            for blk in blocks:
+                x = infer.infer_block(blk, x, out)
+            preds.append(post.infer(infer.infer_non_blocks(head, x, out.embed), out)[0])
+        sch.noise_pred = preds[1] + guide * (preds[0] - preds[1])
+        t = mine.timestep_input(i)
+        my = [T.forward(model, lat, t, c, heads, layers, y=y, clip_fea=clip_fea) for c in (context, context_null)]
+        d = max((my[0] - preds[0]).abs().max().item(), (my[1] - preds[1]).abs().max().item())
+        assert d < 5e-5, f"forward mismatch at step {i}: {d}"
+        sch.step_post()
+        lat = mine.step(i, T.cfg_combine(my[0], my[1], guide), lat)
+        d2 = (lat - sch.latents).abs().max().item()
+        assert d2 < 2e-4, f"scheduler mismatch at step {i}: {d2}"
+        worst = max(worst, d, d2)
+        store[f"noise_pred_{i}"] = sch.noise_pred.numpy()
+        store[f"latents_{i + 1}"] = sch.latents.numpy()
+    meta = dict(latent_shape=latent_shape, dim=dim, heads=heads, ffn=ffn, layers=layers, text_len=text_len, text_dim=text_dim, clip_dim=clip_dim,
+                steps=steps, shift=shift, guide=guide, seed=seed)
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), meta=np.array(repr(meta)), **store)
+    print(f"{name}: {steps} steps, worst |restatement - reference| = {worst:.3e}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
+    ap.add_argument("--only", default=None, help="run only the case of this name")
     a = ap.parse_args()
     G._install_reference(a.ref)
     torch.manual_seed(0)
+    if a.only == "step_clip_i2v_d256":
+        with torch.no_grad():
+            run_clip_i2v_case("step_clip_i2v_d256", (16, 3, 8, 12), 256, 2, 512, 2, 16, 128, 128, 3, 5.0, 5.0, 9, a.out)
+        return
     with torch.no_grad():
+        run_clip_i2v_case("step_clip_i2v_d256", (16, 3, 8, 12), 256, 2, 512, 2, 16, 128, 128, 3, 5.0, 5.0, 9, a.out)
         run_case("step_tiny_d256", (16, 3, 8, 12), 256, 2, 512, 2, 16, 128, 6, 5.0, 5.0, 3, a.out)
         run_case("step_small_d512", (16, 2, 12, 16), 512, 4, 1024, 2, 32, 256, 4, 3.0, 4.0, 5, a.out)
         run_two_expert_case("step_moe_i2v_d256", (16, 3, 8, 12), 256, 2, 512, 1, 16, 128, 6, 5.0, (3.5, 3.0), 0.6, 7, a.out)

@@ -176,6 +176,23 @@ def make_block_weights(dim: int, ffn_dim: int, seed: int = 0, block_index: int =
     return {k: v.to(dtype) for k, v in w.items()}
 
 
+IMAGE_TOKENS = 257  # CLIP tokens in front of the text context (transformer_infer.py:217-218)
+
+
+def make_image_branch_weights(dim: int, seed: int = 0, block_index: int = 0, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """The extra keys of an i2v block with a CLIP image encoder
+    (weights/transformer_weights.py:398-431): `cross_attn.{k_img, v_img}.{weight, bias}`,
+    `cross_attn.norm_k_img.weight`.  Own generator: the t2v keys of a seed do not change."""
+    g = torch.Generator().manual_seed(seed * 1000003 + block_index + 500009)
+    p = f"blocks.{block_index}.cross_attn."
+    w = {}
+    for n in ("k_img", "v_img"):
+        w[p + n + ".weight"] = 0.02 * torch.randn(dim, dim, generator=g)
+        w[p + n + ".bias"] = 0.02 * torch.randn(dim, generator=g)
+    w[p + "norm_k_img.weight"] = 1.0 + 0.1 * torch.randn(dim, generator=g)
+    return {k: v.to(dtype) for k, v in w.items()}
+
+
 def make_head_weights(dim: int, out_dim: int = 64, seed: int = 0, dtype=torch.float32):
     g = torch.Generator().manual_seed(seed * 1000003 + 999983)
     return {
@@ -208,8 +225,11 @@ class BlockTrace:
 def block_forward(x: torch.Tensor, embed0: torch.Tensor, context: torch.Tensor,
                   w: Dict[str, torch.Tensor], cos_sin: torch.Tensor, num_heads: int,
                   block_index: int = 0, trace: Optional[BlockTrace] = None,
-                  attn_fn=sdpa, self_attn_fn=None) -> torch.Tensor:
-    """`WanTransformerInfer.infer_block`, transformer_infer.py:105-128 (t2v branch, no adapters).
+                  attn_fn=sdpa, self_attn_fn=None, image_tokens: int = 0) -> torch.Tensor:
+    """`WanTransformerInfer.infer_block`, transformer_infer.py:105-128 (no adapters).  With
+    `image_tokens` > 0 (i2v with a CLIP image encoder: 257) the first rows of `context` are image
+    tokens with their own k / v projections and a second cross-attention whose output is added to
+    the text one before the output projection (:216-219, 247-269).
 
     x [S,D] (not modified), embed0 [6,D], context [T,D], cos_sin complex [S,1,d/2].
     `self_attn_fn(q,k,v)` lets a sequence-parallel wrapper replace the self-attention call
@@ -242,11 +262,16 @@ def block_forward(x: torch.Tensor, embed0: torch.Tensor, context: torch.Tensor,
     t("x_after_self", x)
     norm3 = layer_norm(x, w[p + "norm3.weight"], w[p + "norm3.bias"])
     t("norm3_out", norm3)
+    context_img, context = (context[:image_tokens], context[image_tokens:]) if image_tokens else (None, context)
     cq = rms_norm(linear(norm3, w[p + "cross_attn.q.weight"], w[p + "cross_attn.q.bias"]), w[p + "cross_attn.norm_q.weight"]).view(-1, H, d)
     ck = rms_norm(linear(context, w[p + "cross_attn.k.weight"], w[p + "cross_attn.k.bias"]), w[p + "cross_attn.norm_k.weight"]).view(-1, H, d)
     cv = linear(context, w[p + "cross_attn.v.weight"], w[p + "cross_attn.v.bias"]).view(-1, H, d)
     t("cross_q", cq.reshape(s, D)); t("cross_k", ck.reshape(-1, D)); t("cross_v", cv.reshape(-1, D))
     cattn = attn_fn(cq, ck, cv)
+    if context_img is not None:
+        ik = rms_norm(linear(context_img, w[p + "cross_attn.k_img.weight"], w[p + "cross_attn.k_img.bias"]), w[p + "cross_attn.norm_k_img.weight"]).view(-1, H, d)
+        iv = linear(context_img, w[p + "cross_attn.v_img.weight"], w[p + "cross_attn.v_img.bias"]).view(-1, H, d)
+        cattn = cattn + attn_fn(cq, ik, iv)
     t("cross_attn_out", cattn)
     attn_out = linear(cattn, w[p + "cross_attn.o.weight"], w[p + "cross_attn.o.bias"])
     t("cross_attn_y", attn_out)

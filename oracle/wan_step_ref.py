@@ -51,6 +51,26 @@ def make_pre_weights(dim: int, in_dim: int = 16, freq_dim: int = 256, text_dim: 
     return w
 
 
+def make_img_emb_weights(dim: int, clip_dim: int, seed: int = 0, dtype=torch.float32):
+    """`img_emb.proj.{0,1,3,4}` of an i2v checkpoint with a CLIP image encoder (weights/pre_weights.py:43-59):
+    LayerNorm(clip_dim), Linear(clip_dim, clip_dim), [GELU], Linear(clip_dim, dim), LayerNorm(dim)."""
+    g = torch.Generator().manual_seed(seed * 1000003 + 616161)
+    w = {"img_emb.proj.0.weight": 1 + 0.1 * torch.randn(clip_dim, generator=g), "img_emb.proj.0.bias": 0.05 * torch.randn(clip_dim, generator=g),
+         "img_emb.proj.1.weight": 0.05 * torch.randn(clip_dim, clip_dim, generator=g), "img_emb.proj.1.bias": 0.02 * torch.randn(clip_dim, generator=g),
+         "img_emb.proj.3.weight": 0.05 * torch.randn(dim, clip_dim, generator=g), "img_emb.proj.3.bias": 0.02 * torch.randn(dim, generator=g),
+         "img_emb.proj.4.weight": 1 + 0.1 * torch.randn(dim, generator=g), "img_emb.proj.4.bias": 0.05 * torch.randn(dim, generator=g)}
+    return {k: v.to(dtype) for k, v in w.items()}
+
+
+def img_emb(pw: Dict[str, torch.Tensor], clip_fea: torch.Tensor) -> torch.Tensor:
+    """pre_infer.py:99-113 (i2v): clip_fea [257, clip_dim] -> image context tokens [257, D]; the
+    GELU between the two Linears is the exact (erf) one."""
+    h = R.layer_norm(clip_fea, pw["img_emb.proj.0.weight"], pw["img_emb.proj.0.bias"])  # eps 1e-6: the plugin default, not nn.LayerNorm's
+    h = F.gelu(R.linear(h, pw["img_emb.proj.1.weight"], pw["img_emb.proj.1.bias"]), approximate="none")
+    h = R.linear(h, pw["img_emb.proj.3.weight"], pw["img_emb.proj.3.bias"])
+    return R.layer_norm(h, pw["img_emb.proj.4.weight"], pw["img_emb.proj.4.bias"])
+
+
 # --------------------------------------------------------------------------- pre / post infer
 def sinusoidal_embedding_1d(dim: int, position: torch.Tensor) -> torch.Tensor:
     """utils.py:205-215: [cos(p * 10000^(-i/half)) || sin(...)], i < half."""
@@ -69,7 +89,7 @@ def patchify(latents: torch.Tensor) -> torch.Tensor:
 
 
 def pre_infer(pw: Dict[str, torch.Tensor], latents: torch.Tensor, t: torch.Tensor, context: torch.Tensor, freq_dim: int = 256,
-              y: Optional[torch.Tensor] = None):
+              y: Optional[torch.Tensor] = None, clip_fea: Optional[torch.Tensor] = None):
     """pre_infer.py:27-126 for task t2v, and for i2v without the CLIP branch (`use_image_encoder`
     false, the Wan2.2 two-expert configuration): `y` = mask + VAE latents [C_y, F, H, W] is
     concatenated to the latents along channels before the patch embedding (:37-53).
@@ -88,6 +108,8 @@ def pre_infer(pw: Dict[str, torch.Tensor], latents: torch.Tensor, t: torch.Tenso
     out = R.linear(context, pw["text_embedding.0.weight"], pw["text_embedding.0.bias"])
     out = F.gelu(out, approximate="tanh")
     ctx = R.linear(out, pw["text_embedding.2.weight"], pw["text_embedding.2.bias"])
+    if clip_fea is not None:  # i2v with a CLIP image encoder: image tokens go in front of the text (:99-113)
+        ctx = torch.cat([img_emb(pw, clip_fea), ctx], dim=0)
     return x, embed, embed0, ctx, (f // PATCH[0], h // PATCH[1], w // PATCH[2])
 
 
@@ -99,13 +121,13 @@ def unpatchify(x: torch.Tensor, grid: Tuple[int, int, int], out_dim: int = 16) -
 
 
 def forward(model: Dict[str, torch.Tensor], latents: torch.Tensor, t: torch.Tensor, context: torch.Tensor, num_heads: int, num_layers: int,
-            cos_sin=None, y: Optional[torch.Tensor] = None) -> torch.Tensor:
+            cos_sin=None, y: Optional[torch.Tensor] = None, clip_fea: Optional[torch.Tensor] = None) -> torch.Tensor:
     """`_infer_cond_uncond` (model.py:447-466): one DiT forward -> noise prediction [16, F, H, W] fp32."""
-    x, embed, embed0, ctx, grid = pre_infer(model, latents, t, context, y=y)
+    x, embed, embed0, ctx, grid = pre_infer(model, latents, t, context, y=y, clip_fea=clip_fea)
     if cos_sin is None:
         cos_sin = R.build_cos_sin(grid, model["patch_embedding.bias"].shape[0] // num_heads)
     for i in range(num_layers):
-        x = R.block_forward(x, embed0, ctx, model, cos_sin, num_heads, block_index=i)
+        x = R.block_forward(x, embed0, ctx, model, cos_sin, num_heads, block_index=i, image_tokens=R.IMAGE_TOKENS if clip_fea is not None else 0)
     y = R.head_forward(x, embed, model)
     return unpatchify(y, grid, model["head.head.bias"].shape[0] // 4).float()
 

@@ -10,7 +10,7 @@ import torch
 import lightx2v_amd as L
 from lightx2v_amd import hip
 from oracle import wan_step_ref as T
-from tests.test_step_oracle import moe_case, step_case
+from tests.test_step_oracle import clip_case, moe_case, step_case
 from tests.util import cos, rel_err
 
 pytestmark = pytest.mark.gpu
@@ -145,6 +145,44 @@ def test_two_expert_i2v_loop_against_reference_trajectory(cuda):
     err, c = rel_err(sch.latents, final), cos(sch.latents, final)
     print(f"\ntwo-expert i2v loop: final-latent max-rel-err {err:.3e}, cosine {c:.6f}")
     assert err <= 3e-2 and c >= 0.9995
+
+
+def test_clip_i2v_loop_against_reference_trajectory(cuda):
+    """Wan2.1 i2v with a CLIP image encoder: img_emb (LN, Linear, exact GELU, Linear, LN) on the 257 image
+    tokens, k_img / v_img / norm_k_img and the second cross-attention in every block."""
+    rec, meta, model = clip_case()
+    cfg = {"dim": meta["dim"], "num_heads": meta["heads"], "num_layers": meta["layers"], "ffn_dim": meta["ffn"], "in_dim": 36, "out_dim": 16,
+           "freq_dim": 256, "task": "i2v", "use_image_encoder": True, "model_cls": "wan2.1", "infer_steps": meta["steps"],
+           "sample_shift": meta["shift"], "sample_guide_scale": meta["guide"], "enable_cfg": True, "run_device": "cuda",
+           "keep_latents_dtype_in_scheduler": True}
+    inputs = {"text_encoder_output": {"context": torch.from_numpy(rec["context"]).to(cuda), "context_null": torch.from_numpy(rec["context_null"]).to(cuda)},
+              "image_encoder_output": {"vae_encoder_out": torch.from_numpy(rec["y"]).to(cuda), "clip_encoder_out": torch.from_numpy(rec["clip_fea"]).to(cuda)}}
+    for fused in (True, False):
+        m = L.WanModel(dict(cfg, fused_block=fused), weight_dict=dict(model))
+        m.to_cuda()
+        sch = L.WanScheduler(cfg)
+        m.set_scheduler(sch)
+        sch.prepare(meta["seed"], meta["latent_shape"], latents=torch.from_numpy(rec["latents0"]))
+        sch.step_pre(0)
+        ctx = m.pre_infer.infer(m.pre_weight, inputs).context
+        want = torch.from_numpy(rec["pre_context"])
+        assert tuple(ctx.shape) == tuple(want.shape) and cos(ctx[:257], want[:257]) >= 0.9995 and cos(ctx[257:], want[257:]) >= 0.9995
+        for i in range(meta["steps"]):
+            sch.step_pre(i)
+            m.infer(inputs)
+            assert cos(sch.noise_pred, torch.from_numpy(rec[f"noise_pred_{i}"])) >= 0.999, (fused, i)
+            sch.step_post()
+        final = torch.from_numpy(rec[f"latents_{meta['steps']}"])
+        err, c = rel_err(sch.latents, final), cos(sch.latents, final)
+        print(f"\nCLIP i2v loop (fused_block={fused}): final-latent max-rel-err {err:.3e}, cosine {c:.6f}")
+        assert err <= 3e-2 and c >= 0.9995
+
+
+def test_gelu_erf_kernel(cuda):
+    x = (3.0 * torch.randn(4096, generator=torch.Generator().manual_seed(4))).to(torch.bfloat16)
+    got = hip.gelu_erf(x.to(cuda)).float().cpu()
+    ref = torch.nn.functional.gelu(x.float(), approximate="none")
+    assert (got - ref).abs().max().item() <= 2.0 ** -8 * max(1.0, ref.abs().max().item())
 
 
 def test_teacache_loop_against_reference_run(cuda):

@@ -40,6 +40,41 @@ def moe_case(name=MOE_CASE):
     return rec, meta, models
 
 
+CLIP_CASE = "step_clip_i2v_d256"
+
+
+def clip_case(name=CLIP_CASE):
+    rec = load_golden(name)
+    meta = ast.literal_eval(str(rec["meta"]))
+    model = {}
+    for i in range(meta["layers"]):
+        model.update(R.make_block_weights(meta["dim"], meta["ffn"], seed=meta["seed"], block_index=i))
+        model.update(R.make_image_branch_weights(meta["dim"], seed=meta["seed"], block_index=i))
+    model.update(R.make_head_weights(meta["dim"], 64, seed=meta["seed"]))
+    model.update(T.make_pre_weights(meta["dim"], 36, 256, meta["text_dim"], seed=meta["seed"]))
+    model.update(T.make_img_emb_weights(meta["dim"], meta["clip_dim"], seed=meta["seed"]))
+    return rec, meta, model
+
+
+def test_clip_i2v_loop_matches_reference_trajectory():
+    """i2v with a CLIP image encoder: 257 image tokens through img_emb in front of the text, k_img /
+    v_img / norm_k_img and the second cross-attention in every block, 36 input channels."""
+    rec, meta, model = clip_case()
+    y, clip_fea = torch.from_numpy(rec["y"]), torch.from_numpy(rec["clip_fea"])
+    lat = torch.from_numpy(rec["latents0"])
+    sch = T.UniPC(meta["steps"], meta["shift"])
+    ctx = T.pre_infer(model, lat, sch.timestep_input(0), torch.from_numpy(rec["context"]), y=y, clip_fea=clip_fea)[3]
+    assert ctx.shape[0] == R.IMAGE_TOKENS + meta["text_len"]
+    assert (ctx - torch.from_numpy(rec["pre_context"])).abs().max().item() <= 2e-5
+    for i in range(meta["steps"]):
+        t = sch.timestep_input(i)
+        c, u = (T.forward(model, lat, t, torch.from_numpy(rec[k]), meta["heads"], meta["layers"], y=y, clip_fea=clip_fea) for k in ("context", "context_null"))
+        noise = T.cfg_combine(c, u, meta["guide"])
+        assert (noise - torch.from_numpy(rec[f"noise_pred_{i}"])).abs().max().item() <= 2e-4, i
+        lat = sch.step(i, noise, lat)
+        assert (lat - torch.from_numpy(rec[f"latents_{i + 1}"])).abs().max().item() <= 5e-4, i
+
+
 def test_two_expert_loop_matches_reference_trajectory():
     rec, meta, models = moe_case()
     lat, traj, picks = T.sample_loop_two_experts(models, meta["boundary"], meta["guides"], torch.from_numpy(rec["latents0"]),
