@@ -40,7 +40,11 @@ MODELS = {
     "wan2.1-t2v-1.3b": (1536, 12, 8960, 30),
     # Wan2.2-I2V-A14B: two experts of the 14B architecture (high-noise / low-noise), in_dim 16 + 20
     "wan2.2-i2v-a14b": (5120, 40, 13824, 40),
+    # Wan2.1-I2V-14B (the model of the reference's published end-to-end rows): 14B blocks + 257 CLIP image tokens
+    # with their own k / v and a second cross-attention, in_dim 16 + 20
+    "wan2.1-i2v-14b": (5120, 40, 13824, 40),
 }
+CLIP_TOKENS, CLIP_DIM = 257, 1280
 MOE_BOUNDARY = 0.9        # i2v switch point (fraction of 1000 training timesteps)
 MOE_GUIDE = [3.5, 3.5]
 MOE_COND_CHANNELS = 20    # mask (4) + VAE latents of the conditioning image (16)
@@ -114,6 +118,11 @@ def build_model(cfg, device, seed):
         wd[p + "norm3.weight"] = torch.ones(D, device=device)
         wd[p + "norm3.bias"] = torch.zeros(D, device=device)
         wd[p + "modulation"] = rn(1, 6, D, std=1.0 / math.sqrt(D), dtype=torch.float32)
+        if cfg["task"] == "i2v" and cfg.get("use_image_encoder", True):
+            for name in ("cross_attn.k_img", "cross_attn.v_img"):
+                wd[p + name + ".weight"] = rn(D, D, std=0.02)
+                wd[p + name + ".bias"] = rn(D, std=0.02, dtype=torch.float32)
+            wd[p + "cross_attn.norm_k_img.weight"] = torch.ones(D, device=device)
         W.blocks[i].load(wd)
         sa, ca, _ = W.blocks[i].compute_phases
         sa.fused_qkv()
@@ -127,6 +136,11 @@ def build_model(cfg, device, seed):
                          "time_embedding.2": (D, D), "time_projection.1": (6 * D, D)}.items():
         pw[name + ".weight"] = rn(o, i, std=0.02)
         pw[name + ".bias"] = rn(o, std=0.02, dtype=torch.float32)
+    if cfg["task"] == "i2v" and cfg.get("use_image_encoder", True):
+        for name, n in (("img_emb.proj.0", CLIP_DIM), ("img_emb.proj.4", D)):
+            pw[name + ".weight"], pw[name + ".bias"] = torch.ones(n, device=device), torch.zeros(n, device=device)
+        for name, (o, i) in {"img_emb.proj.1": (CLIP_DIM, CLIP_DIM), "img_emb.proj.3": (D, CLIP_DIM)}.items():
+            pw[name + ".weight"], pw[name + ".bias"] = rn(o, i, std=0.02), rn(o, std=0.02, dtype=torch.float32)
     model.pre_weight.load(pw)
     return model
 
@@ -428,6 +442,7 @@ def main():
            "cfg_parallel": cfg_p > 1, "cfg_p_group": cfg_group,
            "seq_parallel": seq_p > 1, "seq_p_group": seq_group, "parallel": {"seq_p_size": seq_p, "cfg_p_size": cfg_p, "seq_p_attn_type": "hip_ulysses"}}
     moe = args.model == "wan2.2-i2v-a14b"
+    i2v_clip = args.model == "wan2.1-i2v-14b"
     if moe:
         # a 4-step schedule puts steps 0-1 above the boundary and steps 2-3 below it, so one warm-up
         # and two timed steps run the high-noise expert, then each expert once
@@ -436,6 +451,8 @@ def main():
         experts = [build_model(cfg, dev, seed=1234), build_model(cfg, dev, seed=4321)]  # same seeds on every rank
         model = L.MultiModelStruct(experts, cfg, boundary=MOE_BOUNDARY)
     else:
+        if i2v_clip:
+            cfg.update({"task": "i2v", "use_image_encoder": True, "in_dim": LATENT_CHANNELS + MOE_COND_CHANNELS})
         experts = [build_model(cfg, dev, seed=1234)]  # same seed on every rank: weights are replicated
         model = experts[0]
     sch = L.WanScheduler(cfg)
@@ -448,8 +465,10 @@ def main():
     sch.prepare(0, latent_shape, latents=torch.randn(*latent_shape, generator=g, device=dev, dtype=torch.float32))
     inputs = {"text_encoder_output": {k: torch.randn(1, TEXT_LEN, TEXT_DIM, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
                                       for k in ("context", "context_null")}}
-    if moe:
+    if moe or i2v_clip:
         inputs["image_encoder_output"] = {"vae_encoder_out": torch.randn(MOE_COND_CHANNELS, *latent_shape[1:], generator=g, device=dev, dtype=torch.float32)}
+    if i2v_clip:
+        inputs["image_encoder_output"]["clip_encoder_out"] = torch.randn(CLIP_TOKENS, CLIP_DIM, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
     timers = [AttnTimer(m.transformer_weights.blocks[i].compute_phases[0].self_attn_1) for m in experts for i in range(layers)]
     picks = []
 
@@ -513,7 +532,8 @@ def main():
             "dtype": arithmetic_label(args)[0], "data": "synthetic latents and text features, random-init weights of the named architecture"
                     + ("" if (backend == "nccl" and not share_gpu) else f" [REHEARSAL: backend={backend} share_gpu={share_gpu}, not a measurement]"),
             "config": {"workload": f"{args.model} {args.res} x81f: {S} tokens, full denoise step (pre-infer, {layers} blocks + head, unpatchify) x 2 CFG forwards + CFG combine + UniPC update, text len {TEXT_LEN}"
-                                   + (f"; two resident experts, switch at t = {MOE_BOUNDARY} (experts of the timed steps: {picks[args.warmup:]}), {MOE_COND_CHANNELS} conditioning channels" if moe else ""),
+                                   + (f"; two resident experts, switch at t = {MOE_BOUNDARY} (experts of the timed steps: {picks[args.warmup:]}), {MOE_COND_CHANNELS} conditioning channels" if moe else "")
+                                   + (f"; {CLIP_TOKENS} CLIP image tokens (img_emb MLP + second cross-attention per block), {MOE_COND_CHANNELS} conditioning channels" if i2v_clip else ""),
                        "parallelism": f"cfg_p{cfg_p} x seq_p{seq_p} (ulysses)", "tokens": S, "dim": D, "heads": H, "ffn_dim": F, "layers": layers},
             "step_tflops": step_flops / 1e12,
             "achieved_tflops_per_gpu": step_flops / s_per_step / 1e12 / world,
