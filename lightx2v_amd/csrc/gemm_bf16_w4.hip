@@ -50,7 +50,7 @@ namespace {
 #define W4_DMA_GROUPS 2  // the 8 DMA pieces of a half-step go to MFMA groups 0, D, 2 D, ... (1: the first half of the step, 2: spread over all of it)
 #endif
 #ifndef W4_ABL
-#define W4_ABL 0  // timing ablations (wrong results): 1 no LDS-DMA in the loop, 2 no fragment reads, 4 no wait + barrier per K-tile, 8 no epilogue, 16 no MFMAs, 32 wait for the DMA only (no barrier), 64 barrier only (no waits), 128 no relaxed wait behind an epilogue, 256 every workgroup stages tile (0, 0) (all L2 hits)
+#define W4_ABL 0  // timing ablations (wrong results): 1 no LDS-DMA in the loop, 2 no fragment reads, 4 no wait + barrier per K-tile, 8 no epilogue, 16 no MFMAs, 32 wait for the DMA only (no barrier), 64 barrier only (no waits), 128 no relaxed wait behind an epilogue, 256 every workgroup stages tile (0, 0) (all L2 hits), 512 the epilogue computes but does not store
 #endif
 constexpr int W4_THREADS = 256;
 constexpr int NSLOT = 5;                      // ring of operand K-tiles
@@ -375,7 +375,8 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_bf16_w4_kernel(const GemmPara
           for (int j = 0; j < 8; ++j) v[j] = (float)(__bf16)v[j] + y[j];  // the product is rounded to bf16 before the add, as in the 8-wave kernels
         }
         const u32x4 out = pack8(v);
-        if (gm < p.M && col_ok) *reinterpret_cast<u32x4*>(p.C + (int64_t)gm * p.ldc + gn) = out;
+        if constexpr (W4_ABL & 512) asm volatile("" ::"v"(out));
+        else if (gm < p.M && col_ok) *reinterpret_cast<u32x4*>(p.C + (int64_t)gm * p.ldc + gn) = out;
       }
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
