@@ -357,7 +357,7 @@ def run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu):
         "config": {"workload": f"{args.model} {args.res} x{frames}f: {S} image + {HY_TEXT_LEN} text tokens, full denoise step (pre-infer with token refiner, {layers} double-stream blocks + final layer, unpatchify, distilled-schedule update), no CFG",
                    "parallelism": f"seq_p{seq_p} (ulysses)", "tokens": S, "dim": D, "heads": H, "ffn_dim": F, "layers": layers},
         "step_tflops": step_flops / 1e12, "achieved_tflops_per_gpu": step_flops / s_per_step / 1e12 / world,
-        "exposed_comm_ms_per_step": exposed_ms, "ulysses_chunks": int(os.environ.get("LX2V_ULYSSES_CHUNKS", "2")),
+        "exposed_comm_ms_per_step": exposed_ms, "ulysses_chunks": int(os.environ.get("LX2V_ULYSSES_CHUNKS") or ulysses.default_chunks(seq_p)),
         "roofline": {"kernel": ("attn_fwd_x16_kernel" if args.attn == "bf16" else "attn_fwd_fp8_kernel<false> + quantisation pre-pass") + " (joint image+text attention)",
                      "bound": "mfma", "achieved": achieved, "peak": attn_peak(args),
                      "unit": "TFLOP/s", "frac": achieved / attn_peak(args), "traffic": None,
@@ -538,7 +538,7 @@ def main():
             "step_tflops": step_flops / 1e12,
             "achieved_tflops_per_gpu": step_flops / s_per_step / 1e12 / world,
             # rank 0's compute stream blocked in waits for the Ulysses exchanges, per step (events around each wait)
-            "exposed_comm_ms_per_step": exposed_ms, "ulysses_chunks": int(os.environ.get("LX2V_ULYSSES_CHUNKS", "2")),
+            "exposed_comm_ms_per_step": exposed_ms, "ulysses_chunks": int(os.environ.get("LX2V_ULYSSES_CHUNKS") or ulysses.default_chunks(seq_p)),
             "roofline": {"kernel": "attn_fwd_x16_kernel (self-attention: main launch + 64-row tail launch)" if args.attn == "bf16" else "attn_fwd_fp8_kernel<false> + quantisation pre-pass (self-attention)",
                          "bound": "mfma", "achieved": achieved, "peak": attn_peak(args),
                          "unit": "TFLOP/s", "frac": achieved / attn_peak(args),

@@ -48,6 +48,15 @@ class _Both:
         return True
 
 
+def default_chunks(world: int) -> int:
+    """Head chunks per rank when LX2V_ULYSSES_CHUNKS is not set.  xGMI is point to point: the bytes a
+    rank puts on ONE link per exchange are payload / world^2, the block's compute shrinks only with
+    1 / world, so the exchange weighs most in a group of two (14B at 720p: 0.58 GB per link and block
+    against 15 ms of compute; 0.15 GB / 7.6 ms at four, 36 MB / 3.8 ms at eight).  The exposed part is
+    the first chunk's arrival and the last chunk's return, i.e. 1 / chunks of it."""
+    return 4 if world == 2 else 2
+
+
 def split_heads(heads_per_rank: int, chunks: int) -> List[int]:
     """Head-chunk widths of one rank: `chunks` parts as even as the count allows, the wider ones
     first (5 heads in 2 chunks -> [3, 2]); fewer parts when there are fewer heads."""
@@ -146,7 +155,8 @@ class HipUlyssesAttnWeight(_AttnBase):
         self._dequant = dequant_fn or hip.dequant_fp8_rowwise
         # Head chunks per rank: the exchange of chunk c+1 (and the return of chunk c-1) overlaps the
         # attention of chunk c.  1 = one exchange, no overlap.
-        self.chunks = max(1, int(os.environ.get("LX2V_ULYSSES_CHUNKS", "2")))
+        env = os.environ.get("LX2V_ULYSSES_CHUNKS")
+        self.chunks = max(1, int(env)) if env else 0   # 0: default_chunks(group size) at the call
 
     # ---- exchange core -------------------------------------------------------------------------
     def _exchange_attend(self, q, k, v, attention_module, group, model_cls=None, txt=None, fp8=False) -> Tuple[SegmentedOperand, Optional[torch.Tensor]]:
@@ -178,7 +188,7 @@ class HipUlyssesAttnWeight(_AttnBase):
         sl, heads, d = q.shape
         if heads % world != 0:
             raise ValueError(f"hip_ulysses: num_heads={heads} is not divisible by the sequence-parallel size {world}")
-        widths = split_heads(heads // world, self.chunks)
+        widths = split_heads(heads // world, self.chunks or default_chunks(world))
         dim = heads * d
         lt = 0 if txt is None else txt[0].shape[0]
         dev, dt = q.device, q.dtype

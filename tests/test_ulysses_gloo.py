@@ -58,7 +58,12 @@ def _worker(rank, world, port, cfg_p, seq_p, out_dir, heads_per_rank=2, chunks=2
 
     cfg_idx, seq_idx, seq_group, cfg_group = ulysses.make_groups(cfg_p, seq_p)
     assert rank == cfg_idx * seq_p + seq_idx
-    os.environ["LX2V_ULYSSES_CHUNKS"] = str(chunks)
+    if chunks:
+        os.environ["LX2V_ULYSSES_CHUNKS"] = str(chunks)
+    else:  # unset: the count follows the group size (4 chunks in a group of two, 2 otherwise)
+        os.environ.pop("LX2V_ULYSSES_CHUNKS", None)
+        chunks = ulysses.default_chunks(seq_p)
+        assert chunks == (4 if seq_p == 2 else 2)
     S, H, d = 8 * seq_p, heads_per_rank * seq_p, 128
     g = torch.Generator().manual_seed(100 + cfg_idx)  # cond / uncond branches see different data
     q, k, v = (torch.randn(S, H, d, generator=g) for _ in range(3))
@@ -101,7 +106,9 @@ def _worker(rank, world, port, cfg_p, seq_p, out_dir, heads_per_rank=2, chunks=2
 @pytest.mark.parametrize("cfg_p,seq_p,heads_per_rank,chunks", [(1, 2, 2, 2), (2, 2, 2, 2), (1, 4, 2, 2),
                                                               (1, 2, 5, 2),    # 5 heads per rank -> chunks of 3 + 2 (14B at seq_p = 8)
                                                               (1, 2, 5, 3),    # 2 + 2 + 1
-                                                              (1, 2, 3, 1)])   # one exchange, no overlap
+                                                              (1, 2, 3, 1),    # one exchange, no overlap
+                                                              (1, 2, 8, 0),    # default in a group of two: 4 chunks of 2 heads
+                                                              (1, 4, 3, 0)])   # default in a group of four: 2 chunks, 2 + 1
 def test_ulysses_and_cfg_groups_gloo(tmp_path, cfg_p, seq_p, heads_per_rank, chunks):
     world = cfg_p * seq_p
     mp.spawn(_worker, args=(world, _free_port(), cfg_p, seq_p, str(tmp_path), heads_per_rank, chunks), nprocs=world, join=True)
