@@ -1,0 +1,80 @@
+// Issue cost of VALU instructions placed behind the block-scaled fp8 MFMAs by a lone wave per SIMD:
+// cycles per MFMA with 0..N copies of an instruction mix in every gap.
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/probe_valu_beside_mfma_fp8.hip -o build/probe_valu_fp8
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+template <int I, int N, class F> __device__ __forceinline__ void sfor(F&& f) { if constexpr (I < N) { f(std::integral_constant<int, I>{}); sfor<I + 1, N>(f); } }
+template <int J, int N, int KIND>
+__device__ __forceinline__ void ops(float (&e)[8], float (&x)[8], float (&acc)[4], int (&pk)[4]) {
+  if constexpr (N > 0) {
+    constexpr int n = N - 1;
+    if constexpr (KIND == 0) asm volatile("v_exp_f32 %0, %1" : "=v"(e[(J + n) & 7]) : "v"(x[(J + n) & 7]));
+    if constexpr (KIND == 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc[(J + n) & 3]) : "v"(e[(J + n + 4) & 7]));
+    if constexpr (KIND == 2) asm volatile("v_cvt_pk_fp8_f32 %0, %1, %2" : "+v"(pk[(J + n) & 3]) : "v"(e[(J + n + 2) & 7]), "v"(e[(J + n + 5) & 7]));
+    ops<J, N - 1, KIND>(e, x, acc, pk);
+  }
+}
+template <int J, int NE, int NA, int NC>
+__device__ __forceinline__ void filler(float (&e)[8], float (&x)[8], float (&acc)[4], int (&pk)[4]) {
+  ops<J, NE, 0>(e, x, acc, pk);
+  ops<J, NA, 1>(e, x, acc, pk);
+  ops<J, NC, 2>(e, x, acc, pk);
+}
+// SHAPE 0: 32x32x64 (16 accumulator registers), 1: 16x16x128 (4).  Per gap: NE exps, NA adds, NC fp8 converts.
+template <int SHAPE, int NE, int NA, int NC>
+__global__ __launch_bounds__(256) void k(const int* in, float* out, int iters, long long* cyc) {
+  const int lane = threadIdx.x & 63;
+  i32x8 a[4], b[4];
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 8; ++j) { a[i][j] = in[(i * 512 + j * 64 + lane) & 4095]; b[i][j] = in[(i * 512 + j * 64 + lane + 2048) & 4095]; }
+  int sa = 127, sb = 127;
+  asm volatile("" : "+v"(sa), "+v"(sb));
+  float x[8], e[8], acc[4] = {0.f, 0.f, 0.f, 0.f};
+  int pk[4] = {};
+  for (int i = 0; i < 8; ++i) { x[i] = -0.01f * (lane + i); e[i] = 0.f; }
+  f32x16 c32[4] = {};
+  f32x4 c16[8] = {};
+  const long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+    sfor<0, 32>([&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      if constexpr (SHAPE == 0) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(c32[j & 3]) : "v"(a[j & 3]), "v"(b[(j >> 2) & 3]), "v"(sa), "v"(sb));
+      else asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(c16[j & 7]) : "v"(a[j & 3]), "v"(b[(j >> 2) & 3]), "v"(sa), "v"(sb));
+      filler<j, NE, NA, NC>(e, x, acc, pk);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+  const long long t1 = __builtin_readcyclecounter();
+  if (blockIdx.x == 0 && threadIdx.x == 0) cyc[0] = t1 - t0;
+  float r = acc[0] + acc[1] + acc[2] + acc[3];
+  for (int j = 0; j < 4; ++j) for (int q = 0; q < 16; ++q) r += c32[j][q];
+  for (int j = 0; j < 8; ++j) for (int q = 0; q < 4; ++q) r += c16[j][q];
+  for (int i = 0; i < 8; ++i) r += e[i];
+  for (int i = 0; i < 4; ++i) r += (float)pk[i];
+  out[blockIdx.x * 256 + threadIdx.x] = r;
+}
+int main() {
+  std::vector<int> h(4096, 0x38383838);
+  int* din; float* dout; long long* dc;
+  if (hipMalloc(&din, h.size() * 4) || hipMalloc(&dout, 256 * 256 * 4) || hipMalloc(&dc, 8)) return 1;
+  (void)hipMemcpy(din, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+  auto run = [&](auto kern, const char* name) {
+    for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL(kern, dim3(256), dim3(256), 0, 0, din, dout, 2000, dc); (void)hipDeviceSynchronize(); }
+    long long c = 0; (void)hipMemcpy(&c, dc, 8, hipMemcpyDeviceToHost);
+    printf("%-44s %.2f cycles per MFMA\n", name, (double)c / 2000 / 32);
+  };
+  run(k<0, 0, 0, 0>, "32x32x64 bare");
+  run(k<0, 2, 0, 0>, "32x32x64 + 2 exp"); run(k<0, 4, 0, 0>, "32x32x64 + 4 exp"); run(k<0, 6, 0, 0>, "32x32x64 + 6 exp"); run(k<0, 8, 0, 0>, "32x32x64 + 8 exp");
+  run(k<0, 0, 4, 0>, "32x32x64 + 4 add"); run(k<0, 0, 8, 0>, "32x32x64 + 8 add"); run(k<0, 0, 0, 2>, "32x32x64 + 2 cvt"); run(k<0, 0, 0, 4>, "32x32x64 + 4 cvt");
+  run(k<0, 4, 4, 2>, "32x32x64 + 4 exp 4 add 2 cvt (one softmax share)");
+  run(k<0, 4, 0, 2>, "32x32x64 + 4 exp 2 cvt (row sums elsewhere)");
+  run(k<0, 3, 3, 2>, "32x32x64 + 3 exp 3 add 2 cvt");
+  run(k<1, 0, 0, 0>, "16x16x128 bare");
+  run(k<1, 1, 0, 0>, "16x16x128 + 1 exp"); run(k<1, 2, 0, 0>, "16x16x128 + 2 exp"); run(k<1, 3, 0, 0>, "16x16x128 + 3 exp"); run(k<1, 4, 0, 0>, "16x16x128 + 4 exp");
+  run(k<1, 2, 2, 1>, "16x16x128 + 2 exp 2 add 1 cvt (one softmax share)");
+  run(k<1, 2, 0, 1>, "16x16x128 + 2 exp 1 cvt");
+  return 0;
+}
