@@ -54,6 +54,17 @@ int lx2v_ln_modulate_bf16(const uint16_t* x, int64_t ldx, const float* ln_w, con
                           const float* scale, const float* shift, uint16_t* out, int64_t ldo,
                           int64_t rows, int dim, float eps, void* stream);
 
+/* Same with a per-token part of the modulation: scale_rows / shift_rows are bf16 [rows, dim] (row
+ * stride ld_rows) and are added to the scale / shift vectors (both required) before use.
+ * The reference reaches this by broadcasting (modulation [1,6,D] + embed0 [S,6,D]) when the timestep is
+ * a per-token vector (Wan2.2 ti2v)
+ *                 lightx2v/models/networks/wan/infer/transformer_infer.py:130-137, 157
+ *                 lightx2v/models/schedulers/wan/scheduler.py:388-392. */
+int lx2v_ln_modulate_rows_bf16(const uint16_t* x, int64_t ldx, const float* ln_w, const float* ln_b,
+                               const float* scale, const float* shift, const uint16_t* scale_rows,
+                               const uint16_t* shift_rows, int64_t ld_rows, uint16_t* out, int64_t ldo,
+                               int64_t rows, int dim, float eps, void* stream);
+
 /* ---- RMSNorm over the whole row (+ optional per-head interleaved-pair RoPE) ----------------
  * y = x * rsqrt(mean(x^2) + eps) * w ; then for each head of `head_dim` columns and each pair
  * i: (y[2i], y[2i+1]) *= (cos[r,i] + j sin[r,i]).  rope_cos_sin is fp32 [rows, head_dim]
@@ -78,6 +89,12 @@ int lx2v_rmsnorm_rope_bf16(const uint16_t* x, int64_t ldx, const float* w, int d
  * Replaces transformer_infer.py:209-213, 279, 312-316. */
 int lx2v_gate_residual_bf16(uint16_t* x, int64_t ldx, const uint16_t* y, int64_t ldy,
                             const float* gate, int64_t rows, int dim, void* stream);
+
+/* x += y * (gate + gate_rows[r, :]) with a per-token part gate_rows (bf16 [rows, dim], row stride
+ * ld_rows): the per-token form of the same lines (see lx2v_ln_modulate_rows_bf16). */
+int lx2v_gate_residual_rows_bf16(uint16_t* x, int64_t ldx, const uint16_t* y, int64_t ldy,
+                                 const float* gate, const uint16_t* gate_rows, int64_t ld_rows,
+                                 int64_t rows, int dim, void* stream);
 
 /* ---- GELU (tanh approximation), elementwise -------------------------------------------------
  * Replaces torch.nn.functional.gelu(approximate="tanh")  transformer_infer.py:305. */

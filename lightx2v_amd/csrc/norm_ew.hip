@@ -32,6 +32,7 @@ template <int NC>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(
     const uint16_t* __restrict__ x, int64_t ldx, const float* __restrict__ ln_w,
     const float* __restrict__ ln_b, const float* __restrict__ scale, const float* __restrict__ shift,
+    const uint16_t* __restrict__ scale_rows, const uint16_t* __restrict__ shift_rows, int64_t ld_rows,
     uint16_t* __restrict__ out, int64_t ldo, int64_t rows, int dim, float eps) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
@@ -77,8 +78,20 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(
       }
     }
     if (scale != nullptr) {
-      const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + col), s1 = *reinterpret_cast<const f32x4*>(scale + col + 4);
-      const f32x4 h0 = *reinterpret_cast<const f32x4*>(shift + col), h1 = *reinterpret_cast<const f32x4*>(shift + col + 4);
+      f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + col), s1 = *reinterpret_cast<const f32x4*>(scale + col + 4);
+      f32x4 h0 = *reinterpret_cast<const f32x4*>(shift + col), h1 = *reinterpret_cast<const f32x4*>(shift + col + 4);
+      if (scale_rows != nullptr) {  // per-token part of the modulation (bf16 rows), added to the vectors
+        float sr[8], hr[8];
+        unpack8(*reinterpret_cast<const u32x4*>(scale_rows + row * ld_rows + col), sr);
+        unpack8(*reinterpret_cast<const u32x4*>(shift_rows + row * ld_rows + col), hr);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          s0[i] += sr[i];
+          s1[i] += sr[i + 4];
+          h0[i] += hr[i];
+          h1[i] += hr[i + 4];
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         y[i] = y[i] * (1.0f + s0[i]) + h0[i];
@@ -164,7 +177,8 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(
 
 __global__ __launch_bounds__(256) void gate_residual_kernel(uint16_t* __restrict__ x, int64_t ldx,
                                                             const uint16_t* __restrict__ y, int64_t ldy,
-                                                            const float* __restrict__ gate, int64_t rows, int dim) {
+                                                            const float* __restrict__ gate, const uint16_t* __restrict__ gate_rows, int64_t ld_rows,
+                                                            int64_t rows, int dim) {
   const int nchunks = dim >> 3;
   const int64_t total = rows * nchunks;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -174,7 +188,16 @@ __global__ __launch_bounds__(256) void gate_residual_kernel(uint16_t* __restrict
     unpack8(*reinterpret_cast<const u32x4*>(x + row * ldx + col), a);
     unpack8(*reinterpret_cast<const u32x4*>(y + row * ldy + col), b);
     if (gate != nullptr) {
-      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gate + col), g1 = *reinterpret_cast<const f32x4*>(gate + col + 4);
+      f32x4 g0 = *reinterpret_cast<const f32x4*>(gate + col), g1 = *reinterpret_cast<const f32x4*>(gate + col + 4);
+      if (gate_rows != nullptr) {  // per-token part of the gate (bf16 rows)
+        float gr[8];
+        unpack8(*reinterpret_cast<const u32x4*>(gate_rows + row * ld_rows + col), gr);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          g0[j] += gr[j];
+          g1[j] += gr[j + 4];
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         a[j] += b[j] * g0[j];
@@ -261,9 +284,9 @@ int ew_grid(int64_t work_items) {
     default: hipLaunchKernelGGL(KERNEL<16>, grid, block, 0, st, __VA_ARGS__); break;      \
   }
 
-extern "C" int lx2v_ln_modulate_bf16(const uint16_t* x, int64_t ldx, const float* ln_w, const float* ln_b,
-                                     const float* scale, const float* shift, uint16_t* out, int64_t ldo,
-                                     int64_t rows, int dim, float eps, void* stream) {
+static int ln_modulate_launch(const uint16_t* x, int64_t ldx, const float* ln_w, const float* ln_b, const float* scale, const float* shift,
+                              const uint16_t* scale_rows, const uint16_t* shift_rows, int64_t ld_rows, uint16_t* out, int64_t ldo,
+                              int64_t rows, int dim, float eps, void* stream) {
   LX2V_REQUIRE(rows == 0 || (x && out), LX2V_EINVAL, "ln_modulate: null tensor");
   LX2V_REQUIRE(rows >= 0 && dim > 0, LX2V_EINVAL, "ln_modulate: bad shape rows=%lld dim=%d", (long long)rows, dim);
   LX2V_REQUIRE(dim % 8 == 0 && dim <= 8192, LX2V_EUNSUP, "ln_modulate: dim=%d must be a multiple of 8 and <= 8192", dim);
@@ -271,12 +294,29 @@ extern "C" int lx2v_ln_modulate_bf16(const uint16_t* x, int64_t ldx, const float
   LX2V_REQUIRE(lx2v_aligned16(x) && lx2v_aligned16(out), LX2V_EINVAL, "ln_modulate: tensors must be 16-byte aligned");
   LX2V_REQUIRE((ln_w == nullptr) == (ln_b == nullptr), LX2V_EINVAL, "ln_modulate: ln_w and ln_b must both be given or both NULL");
   LX2V_REQUIRE((scale == nullptr) == (shift == nullptr), LX2V_EINVAL, "ln_modulate: scale and shift must both be given or both NULL");
+  LX2V_REQUIRE((scale_rows == nullptr) == (shift_rows == nullptr), LX2V_EINVAL, "ln_modulate: scale_rows and shift_rows must both be given or both NULL");
+  LX2V_REQUIRE(scale_rows == nullptr || (scale != nullptr && ld_rows % 8 == 0 && ld_rows >= dim && lx2v_aligned16(scale_rows) && lx2v_aligned16(shift_rows)), LX2V_EINVAL,
+               "ln_modulate: per-token rows need the scale/shift vectors, 16-byte alignment and a row stride that is a multiple of 8 and >= dim");
   if (rows == 0) return LX2V_OK;
   const dim3 grid((unsigned)((rows + kRowsPerBlock - 1) / kRowsPerBlock)), block(256);
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH_NC(pick_nc(dim), ln_modulate_kernel, x, ldx, ln_w, ln_b, scale, shift, out, ldo, rows, dim, eps);
+  DISPATCH_NC(pick_nc(dim), ln_modulate_kernel, x, ldx, ln_w, ln_b, scale, shift, scale_rows, shift_rows, ld_rows, out, ldo, rows, dim, eps);
   LX2V_CHECK_LAUNCH("ln_modulate");
   return LX2V_OK;
+}
+
+extern "C" int lx2v_ln_modulate_bf16(const uint16_t* x, int64_t ldx, const float* ln_w, const float* ln_b,
+                                     const float* scale, const float* shift, uint16_t* out, int64_t ldo,
+                                     int64_t rows, int dim, float eps, void* stream) {
+  return ln_modulate_launch(x, ldx, ln_w, ln_b, scale, shift, nullptr, nullptr, 0, out, ldo, rows, dim, eps, stream);
+}
+
+extern "C" int lx2v_ln_modulate_rows_bf16(const uint16_t* x, int64_t ldx, const float* ln_w, const float* ln_b,
+                                          const float* scale, const float* shift, const uint16_t* scale_rows,
+                                          const uint16_t* shift_rows, int64_t ld_rows, uint16_t* out, int64_t ldo,
+                                          int64_t rows, int dim, float eps, void* stream) {
+  LX2V_REQUIRE(scale_rows != nullptr, LX2V_EINVAL, "ln_modulate_rows: per-token rows are NULL");
+  return ln_modulate_launch(x, ldx, ln_w, ln_b, scale, shift, scale_rows, shift_rows, ld_rows, out, ldo, rows, dim, eps, stream);
 }
 
 extern "C" int lx2v_rmsnorm_rope_bf16(const uint16_t* x, int64_t ldx, const float* w, int do_norm,
@@ -304,16 +344,29 @@ extern "C" int lx2v_rmsnorm_rope_bf16(const uint16_t* x, int64_t ldx, const floa
   return LX2V_OK;
 }
 
-extern "C" int lx2v_gate_residual_bf16(uint16_t* x, int64_t ldx, const uint16_t* y, int64_t ldy,
-                                       const float* gate, int64_t rows, int dim, void* stream) {
+static int gate_residual_launch(uint16_t* x, int64_t ldx, const uint16_t* y, int64_t ldy, const float* gate, const uint16_t* gate_rows,
+                                int64_t ld_rows, int64_t rows, int dim, void* stream) {
   LX2V_REQUIRE(rows == 0 || (x && y), LX2V_EINVAL, "gate_residual: null tensor");
   LX2V_REQUIRE(rows >= 0 && dim > 0 && dim % 8 == 0, LX2V_EINVAL, "gate_residual: dim=%d must be a positive multiple of 8", dim);
   LX2V_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= dim && ldy >= dim, LX2V_EINVAL, "gate_residual: row strides must be multiples of 8 and >= dim");
   LX2V_REQUIRE(lx2v_aligned16(x) && lx2v_aligned16(y), LX2V_EINVAL, "gate_residual: tensors must be 16-byte aligned");
+  LX2V_REQUIRE(gate_rows == nullptr || (gate != nullptr && ld_rows % 8 == 0 && ld_rows >= dim && lx2v_aligned16(gate_rows)), LX2V_EINVAL,
+               "gate_residual: per-token rows need the gate vector, 16-byte alignment and a row stride that is a multiple of 8 and >= dim");
   if (rows == 0) return LX2V_OK;
-  hipLaunchKernelGGL(gate_residual_kernel, dim3(ew_grid(rows * (dim >> 3))), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, gate, rows, dim);
+  hipLaunchKernelGGL(gate_residual_kernel, dim3(ew_grid(rows * (dim >> 3))), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, gate, gate_rows, ld_rows, rows, dim);
   LX2V_CHECK_LAUNCH("gate_residual");
   return LX2V_OK;
+}
+
+extern "C" int lx2v_gate_residual_bf16(uint16_t* x, int64_t ldx, const uint16_t* y, int64_t ldy,
+                                       const float* gate, int64_t rows, int dim, void* stream) {
+  return gate_residual_launch(x, ldx, y, ldy, gate, nullptr, 0, rows, dim, stream);
+}
+
+extern "C" int lx2v_gate_residual_rows_bf16(uint16_t* x, int64_t ldx, const uint16_t* y, int64_t ldy, const float* gate,
+                                            const uint16_t* gate_rows, int64_t ld_rows, int64_t rows, int dim, void* stream) {
+  LX2V_REQUIRE(gate_rows != nullptr, LX2V_EINVAL, "gate_residual_rows: per-token rows are NULL");
+  return gate_residual_launch(x, ldx, y, ldy, gate, gate_rows, ld_rows, rows, dim, stream);
 }
 
 extern "C" int lx2v_gelu_tanh_bf16(const uint16_t* x, uint16_t* out, int64_t n, void* stream) {

@@ -26,6 +26,8 @@ _SIGNATURES = {
     "lx2v_ln_modulate_bf16": [_P, _I64, _P, _P, _P, _P, _P, _I64, _I64, _I, _F, _P],
     "lx2v_rmsnorm_rope_bf16": [_P, _I64, _P, _I, _P, _I, _P, _I64, _I64, _I, _F, _P],
     "lx2v_gate_residual_bf16": [_P, _I64, _P, _I64, _P, _I64, _I, _P],
+    "lx2v_ln_modulate_rows_bf16": [_P, _I64, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I64, _I, _F, _P],
+    "lx2v_gate_residual_rows_bf16": [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I, _P],
     "lx2v_gelu_tanh_bf16": [_P, _P, _I64, _P],
     "lx2v_gelu_erf_bf16": [_P, _P, _I64, _P],
     "lx2v_gemm_bf16": [_P, _I64, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _I64, _I, _P, _I64, _P, _P],
@@ -152,8 +154,25 @@ def _vec_f32(name: str, t: Optional[torch.Tensor], n: int, like: torch.Tensor) -
 
 
 # ---------------------------------------------------------------------------------------------
+class RowMod:
+    """One of the six modulation terms when the timestep is a per-token vector: a [dim] vector
+    (the block's learned table row, fp32) plus a per-token part `rows` (bf16 [tokens, dim], any row
+    stride: usually a column slice of the [tokens, 6*dim] time projection)."""
+
+    def __init__(self, vec: torch.Tensor, rows: torch.Tensor):
+        self.vec, self.rows = vec, rows
+
+    def checked(self, name: str, n_rows: int, dim: int, like: torch.Tensor):
+        _need_bf16_cuda(name + ".rows", self.rows)
+        if tuple(self.rows.shape) != (n_rows, dim) or self.rows.stride(0) % 8 != 0 or self.rows.data_ptr() % 16 != 0:
+            raise Lx2vError(f"{name}.rows: expected bf16 [{n_rows}, {dim}] with a 16-byte aligned base and a row stride multiple of 8, "
+                            f"got {tuple(self.rows.shape)} stride {self.rows.stride()}")
+        return _vec_f32(name + ".vec", self.vec, dim, like), self.rows
+
+
 def ln_modulate(x: torch.Tensor, ln_w=None, ln_b=None, scale=None, shift=None, eps: float = 1e-6,
                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`scale` / `shift`: fp32 [dim] vectors, or both `RowMod` (per-token modulation)."""
     _need_bf16_cuda("ln_modulate.x", x)
     assert x.dim() == 2
     rows, dim = x.shape
@@ -163,6 +182,17 @@ def ln_modulate(x: torch.Tensor, ln_w=None, ln_b=None, scale=None, shift=None, e
         _need_out("ln_modulate.out", out, (rows, dim), x)
     w = _vec_f32("ln_w", ln_w, dim, x)
     b = _vec_f32("ln_b", ln_b, dim, x)
+    if isinstance(scale, RowMod) or isinstance(shift, RowMod):
+        if not (isinstance(scale, RowMod) and isinstance(shift, RowMod)):
+            raise Lx2vError("ln_modulate: scale and shift must both be per-token (RowMod) or both vectors")
+        sc, sc_rows = scale.checked("scale", rows, dim, x)
+        sh, sh_rows = shift.checked("shift", rows, dim, x)
+        if sc_rows.stride(0) != sh_rows.stride(0):
+            raise Lx2vError("ln_modulate: per-token scale and shift rows must share one row stride")
+        st = load().lx2v_ln_modulate_rows_bf16(x.data_ptr(), x.stride(0), _ptr(w), _ptr(b), _ptr(sc), _ptr(sh), sc_rows.data_ptr(), sh_rows.data_ptr(),
+                                                sc_rows.stride(0), out.data_ptr(), out.stride(0), rows, dim, eps, _stream())
+        _check(st, "lx2v_ln_modulate_rows_bf16")
+        return out
     sc = _vec_f32("scale", scale, dim, x)
     sh = _vec_f32("shift", shift, dim, x)
     st = load().lx2v_ln_modulate_bf16(x.data_ptr(), x.stride(0), _ptr(w), _ptr(b), _ptr(sc), _ptr(sh),
@@ -199,6 +229,11 @@ def gate_residual_(x: torch.Tensor, y: torch.Tensor, gate=None) -> torch.Tensor:
     _need_bf16_cuda("gate_residual.y", y)
     assert x.shape == y.shape and x.dim() == 2
     rows, dim = x.shape
+    if isinstance(gate, RowMod):
+        g, g_rows = gate.checked("gate", rows, dim, x)
+        st = load().lx2v_gate_residual_rows_bf16(x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), _ptr(g), g_rows.data_ptr(), g_rows.stride(0), rows, dim, _stream())
+        _check(st, "lx2v_gate_residual_rows_bf16")
+        return x
     g = _vec_f32("gate", gate, dim, x)
     st = load().lx2v_gate_residual_bf16(x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), _ptr(g), rows, dim, _stream())
     _check(st, "lx2v_gate_residual_bf16")

@@ -252,7 +252,11 @@ class HipMMWeight:
 
     def apply_residual_(self, input_tensor, resid, gate=None, kseg=None):
         """resid <- resid + (x W^T + b) * gate, in place; returns resid.  `kseg` (hip.KSeg): the
-        input's K columns are stored as segments, `input_tensor` being the rows of the first one."""
+        input's K columns are stored as segments, `input_tensor` being the rows of the first one.
+        A per-token gate (hip.RowMod) does not fit the GEMM epilogue's [N] gate vector: the product is
+        formed first and the gated add is its own pass."""
+        if isinstance(gate, hip.RowMod):
+            return hip.gate_residual_(resid, hip.gemm(input_tensor, self.weight_nk, self.bias, kseg=kseg), gate)
         return hip.gemm(input_tensor, self.weight_nk, self.bias, epilogue=hip.EPI_RESIDUAL, resid=resid, gate=gate, out=resid, kseg=kseg)
 
 
@@ -338,6 +342,8 @@ class HipFp8MMWeight(HipMMWeight):
     def apply_residual_(self, input_tensor, resid, gate=None, kseg=None):
         if kseg is not None:
             raise NotImplementedError("hip-fp8: K-segmented operands are built for the bf16 scheme only")
+        if isinstance(gate, hip.RowMod):  # per-token gate: product first, gated add as its own pass
+            return hip.gate_residual_(resid, self._run(input_tensor, hip.EPI_NONE), gate)
         return self._run(input_tensor, hip.EPI_RESIDUAL, resid=resid, gate=gate)
 
 

@@ -205,11 +205,20 @@ class WanTransformerInfer:
         return x
 
     def infer_non_blocks(self, weights, x, e):
-        """Head: LN(x) * (1 + e1) + e0, then Linear D -> out (transformer_infer.py:75-97)."""
+        """Head: LN(x) * (1 + e1) + e0, then Linear D -> out (transformer_infer.py:75-97).  `e` is the
+        time embedding [1, D], or [S, D] when the timestep is a per-token vector (the reference's
+        2-D branch then broadcasts to a per-token modulation)."""
         if e.dim() != 2:
-            raise NotImplementedError("per-token head modulation (diffusion forcing) is outside the Wan t2v/i2v path")
-        mod = weights.head_modulation.tensor.float() + e.float().unsqueeze(1)  # [1, 2, D]
-        shift, scale = mod[0, 0], mod[0, 1]
+            raise NotImplementedError("3-D head modulation (diffusion forcing) is outside the Wan t2v/i2v path")
+        table = weights.head_modulation.tensor.float().reshape(2, -1)
+        if e.shape[0] == 1:
+            mod = table + e.float()
+            shift, scale = mod[0].contiguous(), mod[1].contiguous()
+        else:
+            if e.shape[0] != x.shape[0]:
+                raise ValueError(f"head: {e.shape[0]} embedding rows for {x.shape[0]} tokens")
+            rows = e.to(torch.bfloat16).contiguous()
+            shift, scale = hip.RowMod(table[0].contiguous(), rows), hip.RowMod(table[1].contiguous(), rows)
         x = weights.norm.apply_modulate(x, scale, shift)
         return weights.head.apply(x)
 
@@ -224,12 +233,18 @@ class WanTransformerInfer:
         return self.post_process(x, y, c_gate_msa, pre_infer_out)
 
     def pre_process(self, modulation, embed0):
-        """(modulation[1,6,D] + embed0[6,D]) -> shift, scale, gate, c_shift, c_scale, c_gate, each fp32 [D]
-        (transformer_infer.py:130-142; the sum is taken in fp32 here)."""
-        if embed0.dim() != 2:
-            raise NotImplementedError("per-token timestep embedding (wan2.2 ti2v) is outside the configured path")
-        m = modulation.tensor.float().reshape(6, -1) + embed0.float()
-        return tuple(m[i].contiguous() for i in range(6))
+        """(modulation[1,6,D] + embed0) -> shift, scale, gate, c_shift, c_scale, c_gate
+        (transformer_infer.py:130-142).  embed0 [6, D]: six fp32 [D] vectors (the sum is taken in fp32
+        here).  embed0 [S, 6, D] (per-token timestep, Wan2.2 ti2v: the reference's sum broadcasts):
+        six hip.RowMod = the table row plus the token's slice of embed0, added inside the kernels."""
+        table = modulation.tensor.float().reshape(6, -1)
+        if embed0.dim() == 2:
+            m = table + embed0.float()
+            return tuple(m[i].contiguous() for i in range(6))
+        if embed0.dim() == 3 and embed0.shape[1] == 6:
+            rows = embed0 if embed0.dtype == torch.bfloat16 else embed0.to(torch.bfloat16)
+            return tuple(hip.RowMod(table[i].contiguous(), rows[:, i]) for i in range(6))
+        raise NotImplementedError(f"embed0 of shape {tuple(embed0.shape)}: [6, D] and [S, 6, D] are built (not the diffusion-forcing layout)")
 
     # ---- self attention (transformer_infer.py:144-207) ---------------------------------------
     def infer_self_attn(self, phase, x, shift_msa, scale_msa, gate_msa=None):

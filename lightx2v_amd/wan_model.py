@@ -155,12 +155,22 @@ class WanPreInfer:
         else:
             x = weights.patch_embedding.apply(latents, round_latents=round_now)
         grid = (f // PATCH_SIZE[0], h // PATCH_SIZE[1], w // PATCH_SIZE[2])
-        embed = hip.timestep_embedding(float(sch.timestep_input.flatten()[0]), self.freq_dim, latents.device)
+        # One embedding per DISTINCT timestep.  A per-token timestep vector (Wan2.2 ti2v: 0 on the
+        # conditioning frame's tokens, t elsewhere; scheduler.py:388-392) has few distinct values: the
+        # MLPs run on those, the rows are then dealt to the tokens.
+        t_all = sch.timestep_input.flatten().to("cpu")
+        t_unique, inverse = (t_all, None) if t_all.numel() == 1 else torch.unique(t_all, return_inverse=True)
+        embed = torch.cat([hip.timestep_embedding(float(t), self.freq_dim, latents.device) for t in t_unique], dim=0)
         embed = weights.time_embedding_0.apply(embed)
         embed = hip.silu(embed)
         embed = weights.time_embedding_2.apply(embed)
         embed0 = hip.silu(embed)
         embed0 = weights.time_projection_1.apply(embed0).unflatten(1, (6, self.dim))
+        if inverse is not None:
+            if inverse.numel() != x.shape[0]:
+                raise ValueError(f"per-token timestep: {inverse.numel()} values for {x.shape[0]} tokens")
+            inverse = inverse.to(latents.device)
+            embed, embed0 = embed.index_select(0, inverse), embed0.index_select(0, inverse)  # [S, D], [S, 6, D]
         ctx = context.squeeze(0) if context.dim() == 3 else context
         if ctx.dtype != torch.bfloat16:
             ctx = ctx.to(torch.bfloat16)
@@ -173,7 +183,8 @@ class WanPreInfer:
             h = hip.gelu_erf(weights.proj_1.apply(weights.proj_0.apply(clip_fea)))
             ctx = torch.cat([weights.proj_4.apply(weights.proj_3.apply(h)), ctx], dim=0)
         grid_sizes = GridOutput(tensor=torch.tensor([list(grid)], dtype=torch.int32, device=x.device), tuple=grid)
-        return WanPreInferModuleOutput(embed=embed, grid_sizes=grid_sizes, x=x, embed0=embed0.squeeze(0), context=ctx, adapter_args={"motion_vec": None})
+        return WanPreInferModuleOutput(embed=embed, grid_sizes=grid_sizes, x=x, embed0=embed0.squeeze(0) if inverse is None else embed0, context=ctx,
+                                       adapter_args={"motion_vec": None})
 
 
 class WanPostInfer:

@@ -281,6 +281,47 @@ def run_clip_i2v_case(name, latent_shape, dim, heads, ffn, layers, text_len, tex
     print(f"{name}: {steps} steps, worst |restatement - reference| = {worst:.3e}")
 
 
+def run_per_token_case(name, latent_shape, dim, heads, ffn, layers, text_len, text_dim, seed, out_dir):
+    """One forward with a PER-TOKEN timestep vector (Wan2.2 ti2v: 0 on the tokens of the conditioning
+    frame, t elsewhere; scheduler.py:388-392): the reference's pre-infer then hands the blocks
+    embed0 [S, 6, D] and the head embed [S, D], and its modulation sums broadcast per token."""
+    cfg = {
+        "dim": dim, "num_heads": heads, "num_layers": layers, "ffn_dim": ffn, "in_dim": 16, "out_dim": 16, "freq_dim": 256, "text_len": text_len,
+        "task": "t2v", "model_cls": "wan2.1", "run_device": "cpu", "cpu_offload": False, "seq_parallel": False, "cfg_parallel": False,
+        "self_attn_1_type": "torch_sdpa", "cross_attn_1_type": "torch_sdpa", "cross_attn_2_type": "torch_sdpa", "modulate_type": "torch",
+        "rope_type": "torch", "infer_steps": 4, "target_video_length": 4 * (latent_shape[1] - 1) + 1, "sample_shift": 5.0,
+        "sample_guide_scale": 5.0, "enable_cfg": True, "feature_caching": "NoCaching",
+    }
+    model = build_model(dim, ffn, layers, text_dim, seed)
+    pre_w, blocks, head, pre, infer, post, sch = reference_objects(cfg, model, layers)
+    g = torch.Generator().manual_seed(seed * 7919 + 53)
+    context = torch.randn(text_len, text_dim, generator=g)
+    inputs = {"text_encoder_output": {"context": context.unsqueeze(0), "context_null": context.unsqueeze(0)}}
+    sch.prepare(seed, latent_shape)
+    latents0 = sch.latents.clone()
+    infer.cos_sin = sch.cos_sin
+    sch.step_pre(step_index=1)
+    f, h, w = latent_shape[1], latent_shape[2] // 2, latent_shape[3] // 2
+    mask = torch.ones(f, h, w)
+    mask[0] = 0.0  # the first latent frame is the conditioning image: its tokens see t = 0
+    t_vec = (mask * sch.timestep_input.float()).flatten()
+    sch.timestep_input = t_vec
+    sch.infer_condition = True
+    out = pre.infer(pre_w, inputs)
+    assert out.embed0.shape == (f * h * w, 6, dim) and out.embed.shape == (f * h * w, dim)
+    x = out.x
+    for blk in blocks:
+        x = infer.infer_block(blk, x, out)
+    pred = post.infer(infer.infer_non_blocks(head, x, out.embed), out)[0]
+    mine = T.forward(model, latents0, t_vec, context, heads, layers)
+    d = (mine - pred).abs().max().item()
+    assert d < 5e-5, f"per-token forward mismatch: {d}"
+    meta = dict(latent_shape=latent_shape, dim=dim, heads=heads, ffn=ffn, layers=layers, text_len=text_len, text_dim=text_dim, seed=seed)
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), meta=np.array(repr(meta)), latents0=latents0.numpy(), context=context.numpy(),
+                        t_vec=t_vec.numpy(), noise_pred=pred.numpy(), block_out=x.numpy())
+    print(f"{name}: per-token forward, |restatement - reference| = {d:.3e}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -289,12 +330,17 @@ def main():
     a = ap.parse_args()
     G._install_reference(a.ref)
     torch.manual_seed(0)
+    if a.only == "step_per_token_d256":
+        with torch.no_grad():
+            run_per_token_case("step_per_token_d256", (16, 3, 8, 12), 256, 2, 512, 2, 16, 128, 13, a.out)
+        return
     if a.only == "step_clip_i2v_d256":
         with torch.no_grad():
             run_clip_i2v_case("step_clip_i2v_d256", (16, 3, 8, 12), 256, 2, 512, 2, 16, 128, 128, 3, 5.0, 5.0, 9, a.out)
         return
     with torch.no_grad():
         run_clip_i2v_case("step_clip_i2v_d256", (16, 3, 8, 12), 256, 2, 512, 2, 16, 128, 128, 3, 5.0, 5.0, 9, a.out)
+        run_per_token_case("step_per_token_d256", (16, 3, 8, 12), 256, 2, 512, 2, 16, 128, 13, a.out)
         run_case("step_tiny_d256", (16, 3, 8, 12), 256, 2, 512, 2, 16, 128, 6, 5.0, 5.0, 3, a.out)
         run_case("step_small_d512", (16, 2, 12, 16), 512, 4, 1024, 2, 32, 256, 4, 3.0, 4.0, 5, a.out)
         run_two_expert_case("step_moe_i2v_d256", (16, 3, 8, 12), 256, 2, 512, 1, 16, 128, 6, 5.0, (3.5, 3.0), 0.6, 7, a.out)

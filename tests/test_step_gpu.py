@@ -10,7 +10,7 @@ import torch
 import lightx2v_amd as L
 from lightx2v_amd import hip
 from oracle import wan_step_ref as T
-from tests.test_step_oracle import clip_case, moe_case, step_case
+from tests.test_step_oracle import clip_case, moe_case, per_token_case, step_case
 from tests.util import cos, rel_err
 
 pytestmark = pytest.mark.gpu
@@ -176,6 +176,53 @@ def test_clip_i2v_loop_against_reference_trajectory(cuda):
         err, c = rel_err(sch.latents, final), cos(sch.latents, final)
         print(f"\nCLIP i2v loop (fused_block={fused}): final-latent max-rel-err {err:.3e}, cosine {c:.6f}")
         assert err <= 3e-2 and c >= 0.9995
+
+
+def test_per_token_timestep_forward_against_reference(cuda):
+    """Per-token timestep vector: embeddings per distinct value dealt to the tokens, per-token LN
+    modulation and gates in every block (fused and op-by-op) and in the head."""
+    rec, meta, model = per_token_case()
+    cfg = {"dim": meta["dim"], "num_heads": meta["heads"], "num_layers": meta["layers"], "ffn_dim": meta["ffn"], "in_dim": 16, "out_dim": 16,
+           "freq_dim": 256, "task": "t2v", "infer_steps": 4, "sample_shift": 5.0, "sample_guide_scale": 5.0, "enable_cfg": False, "run_device": "cuda",
+           "keep_latents_dtype_in_scheduler": True}
+    inputs = {"text_encoder_output": {"context": torch.from_numpy(rec["context"]).to(cuda), "context_null": torch.from_numpy(rec["context"]).to(cuda)}}
+    want = torch.from_numpy(rec["noise_pred"])
+    for fused in (True, False):
+        m = L.WanModel(dict(cfg, fused_block=fused), weight_dict=dict(model))
+        m.to_cuda()
+        sch = L.WanScheduler(cfg)
+        m.set_scheduler(sch)
+        sch.prepare(meta["seed"], meta["latent_shape"], latents=torch.from_numpy(rec["latents0"]))
+        sch.step_pre(1)
+        sch.timestep_input = torch.from_numpy(rec["t_vec"])
+        out = m.pre_infer.infer(m.pre_weight, inputs)
+        S = out.x.shape[0]
+        assert tuple(out.embed0.shape) == (S, 6, meta["dim"]) and tuple(out.embed.shape) == (S, meta["dim"])
+        m.infer(inputs)
+        c, err = cos(sch.noise_pred, want), rel_err(sch.noise_pred, want)
+        print(f"\nper-token timestep forward (fused_block={fused}): cosine {c:.6f}, max-rel-err {err:.3e}")
+        assert c >= 0.9995 and err <= 3e-2
+
+
+def test_row_modulation_kernels(cuda):
+    g = torch.Generator().manual_seed(8)
+    rows, dim = 37, 256
+    x = torch.randn(rows, dim, generator=g).to(torch.bfloat16)
+    vec_s, vec_h, vec_g = (0.1 * torch.randn(dim, generator=g) for _ in range(3))
+    e = (0.2 * torch.randn(rows, 6, dim, generator=g)).to(torch.bfloat16)
+    d = e.to(cuda)
+    got = hip.ln_modulate(x.to(cuda), None, None, hip.RowMod(vec_s.to(cuda), d[:, 1]), hip.RowMod(vec_h.to(cuda), d[:, 0]))
+    ref = torch.nn.functional.layer_norm(x.float(), (dim,), eps=1e-6) * (1 + vec_s + e[:, 1].float()) + vec_h + e[:, 0].float()
+    assert (got.float().cpu() - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
+    y = torch.randn(rows, dim, generator=g).to(torch.bfloat16)
+    xx = x.to(cuda).clone()
+    hip.gate_residual_(xx, y.to(cuda), hip.RowMod(vec_g.to(cuda), d[:, 2]))
+    ref = x.float() + y.float() * (vec_g + e[:, 2].float())
+    assert (xx.float().cpu() - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
+    with pytest.raises(hip.Lx2vError):
+        hip.ln_modulate(x.to(cuda), None, None, hip.RowMod(vec_s.to(cuda), d[:, 1]), vec_h.to(cuda))
+    with pytest.raises(hip.Lx2vError):
+        hip.gate_residual_(xx, y.to(cuda), hip.RowMod(vec_g.to(cuda), d[:5, 2]))
 
 
 def test_gelu_erf_kernel(cuda):

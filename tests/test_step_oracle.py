@@ -75,6 +75,30 @@ def test_clip_i2v_loop_matches_reference_trajectory():
         assert (lat - torch.from_numpy(rec[f"latents_{i + 1}"])).abs().max().item() <= 5e-4, i
 
 
+def per_token_case(name="step_per_token_d256"):
+    rec = load_golden(name)
+    meta = ast.literal_eval(str(rec["meta"]))
+    model = {}
+    for i in range(meta["layers"]):
+        model.update(R.make_block_weights(meta["dim"], meta["ffn"], seed=meta["seed"], block_index=i))
+    model.update(R.make_head_weights(meta["dim"], 64, seed=meta["seed"]))
+    model.update(T.make_pre_weights(meta["dim"], 16, 256, meta["text_dim"], seed=meta["seed"]))
+    return rec, meta, model
+
+
+def test_per_token_timestep_forward_matches_reference():
+    """Timestep as a per-token vector (0 on the conditioning frame's tokens): every modulation term
+    becomes a per-token row through the reference's broadcasting sums."""
+    rec, meta, model = per_token_case()
+    t_vec = torch.from_numpy(rec["t_vec"])
+    assert t_vec.unique().numel() == 2 and float(t_vec[0]) == 0.0
+    pred = T.forward(model, torch.from_numpy(rec["latents0"]), t_vec, torch.from_numpy(rec["context"]), meta["heads"], meta["layers"])
+    assert (pred - torch.from_numpy(rec["noise_pred"])).abs().max().item() <= 5e-5
+    # and it differs from the scalar-timestep forward (the conditioning tokens do see another modulation)
+    scalar = T.forward(model, torch.from_numpy(rec["latents0"]), t_vec.max().reshape(1), torch.from_numpy(rec["context"]), meta["heads"], meta["layers"])
+    assert (pred - scalar).abs().max().item() > 1e-3
+
+
 def test_two_expert_loop_matches_reference_trajectory():
     rec, meta, models = moe_case()
     lat, traj, picks = T.sample_loop_two_experts(models, meta["boundary"], meta["guides"], torch.from_numpy(rec["latents0"]),
