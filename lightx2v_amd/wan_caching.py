@@ -1,5 +1,6 @@
-"""TeaCache around the Wan block loop: skip all blocks of a forward when the timestep modulation
-barely moved, re-using the previous forward's residual.
+"""TeaCache and MagCache around the Wan block loop: skip all blocks of a forward and re-use the
+previous forward's residual -- when the timestep modulation barely moved (Tea), or while the
+calibrated magnitude ratios of the skipped steps stay close to one (Mag).
 
 Mirrors `WanTransformerInferTeaCaching`
 (lightx2v/models/networks/wan/infer/feature_caching/transformer_infer.py:25-169): same config keys
@@ -8,6 +9,11 @@ state, same records on the scheduler (`caching_records`, `caching_records_2`).  
 control logic on a [6, D] (or [1, D]) vector -- it is read back once per forward, as the reference
 does with `.cpu().item()`; the token-sized work (residual capture and re-use over [S, D]) runs on
 the HIP element-wise kernel.
+
+`WanTransformerInferMagCaching` mirrors the class of that name (same file, :992-1091): config keys
+`feature_caching: "Mag"`, `magcache_thresh`, `magcache_K`, `magcache_retention_ratio`,
+`magcache_ratios` ([2, infer_steps]: conditional and unconditional branch) and
+`magcache_calibration`; its decision reads nothing from the GPU at all.
 """
 
 from __future__ import annotations
@@ -17,6 +23,13 @@ import torch
 
 from . import hip
 from .wan_block import WanTransformerInfer
+
+
+def _residual(x, ori_x, holder):
+    """x - ori_x as a new bf16 [S, D] tensor on the element-wise kernel; `holder._minus_one` keeps the gate."""
+    if holder._minus_one is None or holder._minus_one.numel() != x.shape[1] or holder._minus_one.device != x.device:
+        holder._minus_one = torch.full((x.shape[1],), -1.0, dtype=torch.float32, device=x.device)
+    return hip.gate_residual_(x.clone(), ori_x, holder._minus_one)
 
 
 class WanTransformerInferTeaCaching(WanTransformerInfer):
@@ -73,9 +86,7 @@ class WanTransformerInferTeaCaching(WanTransformerInfer):
     def infer_calculating(self, blocks, pre_infer_out):
         ori_x = pre_infer_out.x.clone()
         x = super().infer_main_blocks(blocks, pre_infer_out)
-        if self._minus_one is None or self._minus_one.numel() != x.shape[1]:
-            self._minus_one = torch.full((x.shape[1],), -1.0, dtype=torch.float32, device=x.device)
-        residual = hip.gate_residual_(x.clone(), ori_x, self._minus_one)  # x - ori_x
+        residual = _residual(x, ori_x, self)
         if self.scheduler.infer_condition:
             self.previous_residual_even = residual
         else:
@@ -84,3 +95,68 @@ class WanTransformerInferTeaCaching(WanTransformerInfer):
 
     def infer_using_cache(self, x):
         return hip.gate_residual_(x, self.previous_residual_even if self.scheduler.infer_condition else self.previous_residual_odd, None)
+
+
+class WanTransformerInferMagCaching(WanTransformerInfer):
+    def __init__(self, config):
+        super().__init__(config)
+        cfg = self.config
+        self.magcache_thresh = cfg["magcache_thresh"]
+        self.K = cfg["magcache_K"]
+        self.retention_ratio = cfg["magcache_retention_ratio"]
+        self.mag_ratios = np.array(cfg["magcache_ratios"])
+        self.calibration = bool(cfg.get("magcache_calibration", False))
+        if not self.calibration and (self.mag_ratios.ndim != 2 or self.mag_ratios.shape[0] != 2 or self.mag_ratios.shape[1] < cfg["infer_steps"]):
+            raise ValueError(f"magcache_ratios must be [2, >= infer_steps ({cfg['infer_steps']})], got {self.mag_ratios.shape}")
+        self._minus_one = None
+        # calibration output: mean and std of the per-token magnitude ratio of successive residuals,
+        # and their mean cosine distance; index 0 = conditional branch, 1 = unconditional
+        self.norm_ratio, self.norm_std, self.cos_dis = [[1.0], [1.0]], [[0.0], [0.0]], [[0.0], [0.0]]
+        self.clear()
+
+    def clear(self):
+        # {True: conditional branch, False: unconditional branch}
+        self.accumulated_err = {True: 0.0, False: 0.0}
+        self.accumulated_steps = {True: 0, False: 0}
+        self.accumulated_ratio = {True: 1.0, False: 1.0}
+        self.residual_cache = {True: None, False: None}  # bf16 [S, D] on the GPU
+
+    # ---- decision (transformer_infer.py:1009-1033) ----------------------------------------------
+    def should_skip(self, step_index, cond):
+        if self.calibration or step_index < int(self.config["infer_steps"] * self.retention_ratio):
+            return False
+        self.accumulated_ratio[cond] = self.accumulated_ratio[cond] * self.mag_ratios[0 if cond else 1][step_index]
+        self.accumulated_steps[cond] += 1
+        self.accumulated_err[cond] += np.abs(1 - self.accumulated_ratio[cond])
+        if self.accumulated_err[cond] < self.magcache_thresh and self.accumulated_steps[cond] <= self.K:
+            return True
+        self.accumulated_err[cond], self.accumulated_steps[cond], self.accumulated_ratio[cond] = 0, 0, 1.0
+        return False
+
+    def infer_main_blocks(self, blocks, pre_infer_out):
+        if self.should_skip(self.scheduler.step_index, self.scheduler.infer_condition):
+            return self.infer_using_cache(pre_infer_out.x)
+        return self.infer_calculating(blocks, pre_infer_out)
+
+    # ---- block loop with the cache (transformer_infer.py:1045-1079) ------------------------------
+    def infer_calculating(self, blocks, pre_infer_out):
+        cond = self.scheduler.infer_condition
+        ori_x = pre_infer_out.x.clone()
+        x = super().infer_main_blocks(blocks, pre_infer_out)
+        residual = _residual(x, ori_x, self)
+        if self.calibration and self.scheduler.step_index >= 1:
+            self._calibrate(residual, self.residual_cache[cond], int(not cond))
+        self.residual_cache[cond] = residual
+        return x
+
+    def infer_using_cache(self, x):
+        return hip.gate_residual_(x, self.residual_cache[self.scheduler.infer_condition], None)
+
+    @torch.no_grad()
+    def _calibrate(self, cur, prev, index):
+        """Statistics a calibration run prints (transformer_infer.py:1057-1065).  An offline tool, a
+        handful of reductions per forward: plain torch on the bf16 residuals, as the reference."""
+        ratio = cur.norm(dim=-1) / prev.norm(dim=-1)
+        self.norm_ratio[index].append(round(ratio.mean().item(), 5))
+        self.norm_std[index].append(round(ratio.std().item(), 5))
+        self.cos_dis[index].append(round((1 - torch.nn.functional.cosine_similarity(cur, prev, dim=-1, eps=1e-8)).mean().item(), 5))

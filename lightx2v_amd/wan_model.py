@@ -376,8 +376,12 @@ class WanModel:
             from .wan_caching import WanTransformerInferTeaCaching
 
             self.transformer_infer = WanTransformerInferTeaCaching(cfg)
+        elif caching == "Mag":
+            from .wan_caching import WanTransformerInferMagCaching
+
+            self.transformer_infer = WanTransformerInferMagCaching(cfg)
         else:
-            raise NotImplementedError(f"feature_caching={caching!r}: built are 'NoCaching' and 'Tea'")
+            raise NotImplementedError(f"feature_caching={caching!r}: built are 'NoCaching', 'Tea' and 'Mag'")
         self.post_infer = WanPostInfer(cfg)
         self.seq_p_group = cfg.get("seq_p_group") if cfg.get("seq_parallel") else None
         self.cfg_p_group = cfg.get("cfg_p_group") if cfg.get("cfg_parallel") else None

@@ -346,3 +346,63 @@ def sample_loop_teacache(model, latents0, context, context_null, num_heads, num_
         rec.append(c1)
         rec2.append(c2)
     return latents, traj, rec, rec2
+
+
+# --------------------------------------------------------------------------- MagCache
+class MagCache:
+    """Skip logic of `WanTransformerInferMagCaching`
+    (lightx2v/models/networks/wan/infer/feature_caching/transformer_infer.py:992-1091): per CFG branch
+    and from step `infer_steps * retention_ratio` on, the calibrated magnitude ratio of the step
+    (`magcache_ratios[branch][step]`) is multiplied into a running ratio, |1 - ratio| is accumulated,
+    and while that sum stays under the threshold and at most K steps were skipped in a row the
+    blocks are skipped and the previous pass's residual is re-used."""
+
+    def __init__(self, infer_steps: int, thresh: float, K: int, retention_ratio: float, ratios):
+        self.first = int(infer_steps * retention_ratio)
+        self.thresh, self.K, self.ratios = thresh, K, np.array(ratios)
+        self.err = {True: 0.0, False: 0.0}
+        self.steps = {True: 0, False: 0}
+        self.ratio = {True: 1.0, False: 1.0}
+        self.prev_residual = {True: None, False: None}
+
+    def should_calc(self, step_index: int, cond: bool) -> bool:
+        if step_index < self.first:
+            return True
+        self.ratio[cond] = self.ratio[cond] * self.ratios[0 if cond else 1][step_index]
+        self.steps[cond] += 1
+        self.err[cond] += np.abs(1 - self.ratio[cond])
+        if self.err[cond] < self.thresh and self.steps[cond] <= self.K:
+            return False
+        self.err[cond], self.steps[cond], self.ratio[cond] = 0, 0, 1.0
+        return True
+
+
+def sample_loop_magcache(model, latents0, context, context_null, num_heads, num_layers, infer_steps, sample_shift, guide, thresh, K, retention_ratio, ratios):
+    """Denoise loop with MagCache.  Returns (final latents, per-step latents, which forwards ran
+    their blocks: conditional branch, unconditional branch)."""
+    sch = UniPC(infer_steps, sample_shift)
+    mag = MagCache(infer_steps, thresh, K, retention_ratio, ratios)
+    latents, traj, rec, rec2 = latents0, [], [], []
+
+    def fwd(ctx, cond, i, t):
+        x, embed, embed0, c, grid = pre_infer(model, latents, t, ctx)
+        calc = mag.should_calc(i, cond)
+        if calc:
+            cos_sin = R.build_cos_sin(grid, model["patch_embedding.bias"].shape[0] // num_heads)
+            x0 = x.clone()
+            for b in range(num_layers):
+                x = R.block_forward(x, embed0, c, model, cos_sin, num_heads, block_index=b)
+            mag.prev_residual[cond] = x - x0
+        else:
+            x = x + mag.prev_residual[cond]
+        return unpatchify(R.head_forward(x, embed, model), grid, model["head.head.bias"].shape[0] // 4).float(), calc
+
+    for i in range(infer_steps):
+        t = sch.timestep_input(i)
+        cond, c1 = fwd(context, True, i, t)
+        uncond, c2 = fwd(context_null, False, i, t)
+        latents = sch.step(i, cfg_combine(cond, uncond, guide), latents)
+        traj.append(latents)
+        rec.append(c1)
+        rec2.append(c2)
+    return latents, traj, rec, rec2

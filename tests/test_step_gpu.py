@@ -253,4 +253,69 @@ def test_teacache_loop_against_reference_run(cuda):
     sch.clear()
     assert m.transformer_infer.previous_residual_even is None and all(sch.caching_records)
     with pytest.raises(NotImplementedError):
-        _model(meta, model, cuda, feature_caching="Mag")
+        _model(meta, model, cuda, feature_caching="TaylorSeer")
+
+
+def test_magcache_loop_against_reference_run(cuda):
+    """`feature_caching: "Mag"`: the forwards the reference's `WanTransformerInferMagCaching` run
+    skipped are skipped here (both CFG branches), and the trajectory stays with the reference's."""
+    rec, meta, model = step_case("step_magcache_d256")
+    inputs = {"text_encoder_output": {k: torch.from_numpy(rec[k]).to(cuda) for k in ("context", "context_null")}}
+    m, sch = _model(meta, model, cuda, keep_latents_dtype_in_scheduler=True, feature_caching="Mag", magcache_thresh=meta["thresh"], magcache_K=meta["K"],
+                    magcache_retention_ratio=meta["retention_ratio"], magcache_ratios=meta["ratios"], magcache_calibration=False)
+    infer = m.transformer_infer
+    assert type(infer).__name__ == "WanTransformerInferMagCaching" and sch.transformer_infer is infer
+    ran = {True: [], False: []}
+    real = infer.infer_calculating
+
+    def traced(*a, **k):
+        ran[sch.infer_condition][-1] = True
+        return real(*a, **k)
+
+    real_main = infer.infer_main_blocks
+
+    def main(*a, **k):
+        ran[sch.infer_condition].append(False)
+        return real_main(*a, **k)
+
+    infer.infer_calculating, infer.infer_main_blocks = traced, main
+    sch.prepare(meta["seed"], meta["latent_shape"], latents=torch.from_numpy(rec["latents0"]))
+    for i in range(meta["steps"]):
+        sch.step_pre(i)
+        m.infer(inputs)
+        sch.step_post()
+        assert cos(sch.latents, torch.from_numpy(rec[f"latents_{i + 1}"])) >= 0.999, i
+    assert ran[True] == rec["records"].tolist() and ran[False] == rec["records_2"].tolist()
+    final = torch.from_numpy(rec[f"latents_{meta['steps']}"])
+    print(f"\nmagcache loop: ran {''.join('C' if r else '-' for r in ran[True])}, final-latent max-rel-err {rel_err(sch.latents, final):.3e}")
+    assert rel_err(sch.latents, final) <= 5e-2
+    sch.clear()
+    assert infer.residual_cache == {True: None, False: None} and infer.accumulated_steps == {True: 0, False: 0}
+    with pytest.raises(ValueError):
+        _model(meta, model, cuda, feature_caching="Mag", magcache_thresh=0.1, magcache_K=2, magcache_retention_ratio=0.2, magcache_ratios=[[1.0] * 3, [1.0] * 3])
+
+
+def test_magcache_calibration_statistics(cuda):
+    """Calibration mode never skips and records, per branch and step, mean and std of the per-token
+    norm ratio of successive residuals and their mean cosine distance (fp32 torch on the same
+    residuals as the check; transformer_infer.py:1057-1064)."""
+    rec, meta, model = step_case("step_magcache_d256")
+    inputs = {"text_encoder_output": {k: torch.from_numpy(rec[k]).to(cuda) for k in ("context", "context_null")}}
+    m, sch = _model(meta, model, cuda, keep_latents_dtype_in_scheduler=True, feature_caching="Mag", magcache_thresh=meta["thresh"], magcache_K=meta["K"],
+                    magcache_retention_ratio=meta["retention_ratio"], magcache_ratios=[], magcache_calibration=True)
+    infer = m.transformer_infer
+    sch.prepare(meta["seed"], meta["latent_shape"], latents=torch.from_numpy(rec["latents0"]))
+    kept = []
+    for i in range(3):
+        sch.step_pre(i)
+        m.infer(inputs)
+        kept.append(infer.residual_cache[True].float().cpu())
+        sch.step_post()
+        # without skipping, the loop is the plain loop: compare with the cache-free start of the trajectory
+        if i < 2:
+            assert cos(sch.latents, torch.from_numpy(rec[f"latents_{i + 1}"])) >= 0.999
+    assert len(infer.norm_ratio[0]) == 3 and len(infer.norm_ratio[1]) == 3 and len(infer.cos_dis[0]) == 3
+    ratio = kept[2].norm(dim=-1) / kept[1].norm(dim=-1)
+    assert abs(infer.norm_ratio[0][2] - ratio.mean().item()) < 2e-2 and abs(infer.norm_std[0][2] - ratio.std().item()) < 2e-2
+    want = (1 - torch.nn.functional.cosine_similarity(kept[2], kept[1], dim=-1)).mean().item()
+    assert abs(infer.cos_dis[0][2] - want) < 2e-2

@@ -206,3 +206,35 @@ def test_teacache_loop_matches_reference_run():
     assert not all(r1) and sum(r1) > 2
     for i, lat in enumerate(traj):
         assert (lat - torch.from_numpy(rec[f"latents_{i + 1}"])).abs().max().item() < 2e-4
+
+
+def test_magcache_loop_matches_reference_run():
+    """The MagCache restatement against the reference's `WanTransformerInferMagCaching` run (ratios:
+    the first 12 entries of the lists the reference ships): same forwards skipped on both CFG
+    branches, same latents after every step."""
+    rec, meta, model = step_case("step_magcache_d256")
+    final, traj, r1, r2 = T.sample_loop_magcache(model, torch.from_numpy(rec["latents0"]), torch.from_numpy(rec["context"]), torch.from_numpy(rec["context_null"]),
+                                                 meta["heads"], meta["layers"], meta["steps"], meta["shift"], meta["guide"], meta["thresh"], meta["K"],
+                                                 meta["retention_ratio"], meta["ratios"])
+    assert r1 == rec["records"].tolist() and r2 == rec["records_2"].tolist()
+    assert not all(r1) and sum(r1) > 2 and all(r1[: int(meta["steps"] * meta["retention_ratio"])])
+    for i, lat in enumerate(traj):
+        assert (lat - torch.from_numpy(rec[f"latents_{i + 1}"])).abs().max().item() < 2e-4
+
+
+def test_magcache_decision_is_pure_host_logic():
+    """The product's skip decision (no GPU involved) against the restatement's, over the shipped-ratio
+    prefix and a few thresholds, both branches interleaved as the CFG loop calls them."""
+    from lightx2v_amd.wan_caching import WanTransformerInferMagCaching
+
+    rec, meta, _ = step_case("step_magcache_d256")
+    for thresh, K in ((0.12, 2), (0.04, 4), (1.0, 1), (0.0, 3)):
+        mine = WanTransformerInferMagCaching.__new__(WanTransformerInferMagCaching)
+        mine.config = {"infer_steps": meta["steps"]}
+        mine.magcache_thresh, mine.K, mine.retention_ratio, mine.calibration = thresh, K, meta["retention_ratio"], False
+        mine.mag_ratios = np.array(meta["ratios"])
+        mine.clear()
+        ref = T.MagCache(meta["steps"], thresh, K, meta["retention_ratio"], meta["ratios"])
+        for i in range(meta["steps"]):
+            for cond in (True, False):
+                assert mine.should_skip(i, cond) == (not ref.should_calc(i, cond)), (thresh, K, i, cond)
