@@ -65,6 +65,17 @@ int lx2v_ln_modulate_rows_bf16(const uint16_t* x, int64_t ldx, const float* ln_w
                                const uint16_t* shift_rows, int64_t ld_rows, uint16_t* out, int64_t ldo,
                                int64_t rows, int dim, float eps, void* stream);
 
+/* The same LayerNorm + modulation (scale_rows / shift_rows may be NULL: vectors only) whose result
+ * leaves as OCP e4m3 rows `out` (row stride ldo bytes) with one fp32 scale per row, row_scale[r] =
+ * max|row r| / 448: the bytes and scales lx2v_quant_fp8_rowwise gives for the bf16 result, without
+ * that result's trip through memory.  Replaces, for a quantised Linear fed by a LayerNorm, the
+ * reference's separate activation quantisation
+ *                 lightx2v/common/ops/mm/mm_weight.py:492-501 (act_quant_fp8_perchannel_sym_*). */
+int lx2v_ln_modulate_quant_fp8(const uint16_t* x, int64_t ldx, const float* ln_w, const float* ln_b,
+                               const float* scale, const float* shift, const uint16_t* scale_rows,
+                               const uint16_t* shift_rows, int64_t ld_rows, uint8_t* out, int64_t ldo, float* row_scale,
+                               int64_t rows, int dim, float eps, void* stream);
+
 /* ---- RMSNorm over the whole row (+ optional per-head interleaved-pair RoPE) ----------------
  * y = x * rsqrt(mean(x^2) + eps) * w ; then for each head of `head_dim` columns and each pair
  * i: (y[2i], y[2i+1]) *= (cos[r,i] + j sin[r,i]).  rope_cos_sin is fp32 [rows, head_dim]

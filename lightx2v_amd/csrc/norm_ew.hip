@@ -28,12 +28,17 @@ LX2V_DEVICE void load_row(const uint16_t* __restrict__ p, int nchunks, int lane,
 }
 
 // out = (LN(x) * w + b) * (1 + scale) + shift
-template <int NC>
+// Q8: the bf16-rounded result is not written; the row is quantised to OCP e4m3 with one scale per
+// row (qscale[row] = max|row| / 448, out8 = row / qscale) while it is still in registers -- the
+// bytes and scales are those the row-wise quantisation kernel produces from the bf16 output.  This
+// file is built with fast-math, so the two quotients are formed in double precision and rounded
+// once: that is the correctly rounded single-precision quotient.
+template <int NC, bool Q8>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(
     const uint16_t* __restrict__ x, int64_t ldx, const float* __restrict__ ln_w,
     const float* __restrict__ ln_b, const float* __restrict__ scale, const float* __restrict__ shift,
     const uint16_t* __restrict__ scale_rows, const uint16_t* __restrict__ shift_rows, int64_t ld_rows,
-    uint16_t* __restrict__ out, int64_t ldo, int64_t rows, int dim, float eps) {
+    uint16_t* __restrict__ out, int64_t ldo, int64_t rows, int dim, float eps, uint8_t* __restrict__ out8, float* __restrict__ qscale) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -60,6 +65,7 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(
   }
   const float rstd = rsqrtf(wave_sum(ss) / (float)dim + eps);
 
+  float amax = 0.f;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const int ch = lane + 64 * c;
@@ -98,7 +104,37 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(
         y[i + 4] = y[i + 4] * (1.0f + s1[i]) + h1[i];
       }
     }
-    *reinterpret_cast<u32x4*>(out + row * ldo + col) = pack8(y);
+    if constexpr (Q8) {
+      unpack8(pack8(y), r.f[c]);  // the bf16 values the unfused path would have stored
+#pragma unroll
+      for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(r.f[c][i]));
+    } else {
+      *reinterpret_cast<u32x4*>(out + row * ldo + col) = pack8(y);
+    }
+  }
+  if constexpr (Q8) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+    // (the widened operands pass through empty asm statements: a double quotient of two widened
+    // floats would otherwise be narrowed back to a -- here approximate -- single-precision division)
+    double amax_d = (double)fmaxf(amax, 1e-12f);
+    asm volatile("" : "+v"(amax_d));
+    const float sc = (float)(amax_d / 448.0);
+    double sc_d = (double)sc;
+    asm volatile("" : "+v"(sc_d));
+    const float inv = (float)(1.0 / sc_d);
+    if (lane == 0) qscale[row] = sc;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch >= nchunks) continue;
+      const float* f = r.f[c];
+      int lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, 0, false);
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, lo, true);
+      int hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * inv, f[5] * inv, 0, false);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] * inv, f[7] * inv, hi, true);
+      *reinterpret_cast<u32x2*>(out8 + row * ldo + (int64_t)ch * 8) = u32x2{(uint32_t)lo, (uint32_t)hi};
+    }
   }
 }
 
@@ -284,14 +320,20 @@ int ew_grid(int64_t work_items) {
     default: hipLaunchKernelGGL(KERNEL<16>, grid, block, 0, st, __VA_ARGS__); break;      \
   }
 
+namespace {
+template <int NC> constexpr auto ln_modulate_bf16_kernel = ln_modulate_kernel<NC, false>;
+template <int NC> constexpr auto ln_modulate_q8_kernel = ln_modulate_kernel<NC, true>;
+}  // namespace
+
+// out8 == NULL: bf16 rows to `out`; otherwise e4m3 rows to `out8` (row stride ldo, in bytes) and their scales to `qscale`.
 static int ln_modulate_launch(const uint16_t* x, int64_t ldx, const float* ln_w, const float* ln_b, const float* scale, const float* shift,
                               const uint16_t* scale_rows, const uint16_t* shift_rows, int64_t ld_rows, uint16_t* out, int64_t ldo,
-                              int64_t rows, int dim, float eps, void* stream) {
-  LX2V_REQUIRE(rows == 0 || (x && out), LX2V_EINVAL, "ln_modulate: null tensor");
+                              int64_t rows, int dim, float eps, void* stream, uint8_t* out8 = nullptr, float* qscale = nullptr) {
+  LX2V_REQUIRE(rows == 0 || (x && (out || (out8 && qscale))), LX2V_EINVAL, "ln_modulate: null tensor");
   LX2V_REQUIRE(rows >= 0 && dim > 0, LX2V_EINVAL, "ln_modulate: bad shape rows=%lld dim=%d", (long long)rows, dim);
   LX2V_REQUIRE(dim % 8 == 0 && dim <= 8192, LX2V_EUNSUP, "ln_modulate: dim=%d must be a multiple of 8 and <= 8192", dim);
   LX2V_REQUIRE(ldx % 8 == 0 && ldo % 8 == 0 && ldx >= dim && ldo >= dim, LX2V_EINVAL, "ln_modulate: row strides must be multiples of 8 and >= dim");
-  LX2V_REQUIRE(lx2v_aligned16(x) && lx2v_aligned16(out), LX2V_EINVAL, "ln_modulate: tensors must be 16-byte aligned");
+  LX2V_REQUIRE(lx2v_aligned16(x) && lx2v_aligned16(out) && (reinterpret_cast<uintptr_t>(out8) & 7u) == 0, LX2V_EINVAL, "ln_modulate: tensors must be 16-byte aligned (e4m3 rows: 8-byte)");
   LX2V_REQUIRE((ln_w == nullptr) == (ln_b == nullptr), LX2V_EINVAL, "ln_modulate: ln_w and ln_b must both be given or both NULL");
   LX2V_REQUIRE((scale == nullptr) == (shift == nullptr), LX2V_EINVAL, "ln_modulate: scale and shift must both be given or both NULL");
   LX2V_REQUIRE((scale_rows == nullptr) == (shift_rows == nullptr), LX2V_EINVAL, "ln_modulate: scale_rows and shift_rows must both be given or both NULL");
@@ -300,7 +342,11 @@ static int ln_modulate_launch(const uint16_t* x, int64_t ldx, const float* ln_w,
   if (rows == 0) return LX2V_OK;
   const dim3 grid((unsigned)((rows + kRowsPerBlock - 1) / kRowsPerBlock)), block(256);
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH_NC(pick_nc(dim), ln_modulate_kernel, x, ldx, ln_w, ln_b, scale, shift, scale_rows, shift_rows, ld_rows, out, ldo, rows, dim, eps);
+  if (out8 == nullptr) {
+    DISPATCH_NC(pick_nc(dim), ln_modulate_bf16_kernel, x, ldx, ln_w, ln_b, scale, shift, scale_rows, shift_rows, ld_rows, out, ldo, rows, dim, eps, out8, qscale);
+  } else {
+    DISPATCH_NC(pick_nc(dim), ln_modulate_q8_kernel, x, ldx, ln_w, ln_b, scale, shift, scale_rows, shift_rows, ld_rows, out, ldo, rows, dim, eps, out8, qscale);
+  }
   LX2V_CHECK_LAUNCH("ln_modulate");
   return LX2V_OK;
 }
@@ -317,6 +363,14 @@ extern "C" int lx2v_ln_modulate_rows_bf16(const uint16_t* x, int64_t ldx, const 
                                           int64_t rows, int dim, float eps, void* stream) {
   LX2V_REQUIRE(scale_rows != nullptr, LX2V_EINVAL, "ln_modulate_rows: per-token rows are NULL");
   return ln_modulate_launch(x, ldx, ln_w, ln_b, scale, shift, scale_rows, shift_rows, ld_rows, out, ldo, rows, dim, eps, stream);
+}
+
+extern "C" int lx2v_ln_modulate_quant_fp8(const uint16_t* x, int64_t ldx, const float* ln_w, const float* ln_b,
+                                          const float* scale, const float* shift, const uint16_t* scale_rows,
+                                          const uint16_t* shift_rows, int64_t ld_rows, uint8_t* out, int64_t ldo, float* row_scale,
+                                          int64_t rows, int dim, float eps, void* stream) {
+  LX2V_REQUIRE(rows == 0 || (out && row_scale), LX2V_EINVAL, "ln_modulate_quant_fp8: null output");
+  return ln_modulate_launch(x, ldx, ln_w, ln_b, scale, shift, scale_rows, shift_rows, ld_rows, nullptr, ldo, rows, dim, eps, stream, out, row_scale);
 }
 
 extern "C" int lx2v_rmsnorm_rope_bf16(const uint16_t* x, int64_t ldx, const float* w, int do_norm,

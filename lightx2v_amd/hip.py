@@ -27,6 +27,7 @@ _SIGNATURES = {
     "lx2v_rmsnorm_rope_bf16": [_P, _I64, _P, _I, _P, _I, _P, _I64, _I64, _I, _F, _P],
     "lx2v_gate_residual_bf16": [_P, _I64, _P, _I64, _P, _I64, _I, _P],
     "lx2v_ln_modulate_rows_bf16": [_P, _I64, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I64, _I, _F, _P],
+    "lx2v_ln_modulate_quant_fp8": [_P, _I64, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _I64, _I, _F, _P],
     "lx2v_gate_residual_rows_bf16": [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I, _P],
     "lx2v_gelu_tanh_bf16": [_P, _P, _I64, _P],
     "lx2v_gelu_erf_bf16": [_P, _P, _I64, _P],
@@ -170,25 +171,52 @@ class RowMod:
         return _vec_f32(name + ".vec", self.vec, dim, like), self.rows
 
 
+class QuantRows:
+    """An activation already in the W8A8 operand form: e4m3 rows `q` [rows, dim] and one fp32 scale
+    per row (x ~= q * scale), as `quant_fp8_rowwise` returns them."""
+
+    def __init__(self, q: torch.Tensor, scale: torch.Tensor):
+        self.q, self.scale = q, scale
+
+    @property
+    def shape(self):
+        return self.q.shape
+
+
 def ln_modulate(x: torch.Tensor, ln_w=None, ln_b=None, scale=None, shift=None, eps: float = 1e-6,
-                out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """`scale` / `shift`: fp32 [dim] vectors, or both `RowMod` (per-token modulation)."""
+                out: Optional[torch.Tensor] = None, quant: bool = False):
+    """`scale` / `shift`: fp32 [dim] vectors, or both `RowMod` (per-token modulation).
+    `quant`: return the result as `QuantRows` (e4m3 rows + per-row scales, the values
+    `quant_fp8_rowwise` gives for the bf16 result) instead of a bf16 tensor."""
     _need_bf16_cuda("ln_modulate.x", x)
     assert x.dim() == 2
     rows, dim = x.shape
-    if out is None:
-        out = torch.empty((rows, dim), dtype=x.dtype, device=x.device)
-    else:
-        _need_out("ln_modulate.out", out, (rows, dim), x)
     w = _vec_f32("ln_w", ln_w, dim, x)
     b = _vec_f32("ln_b", ln_b, dim, x)
-    if isinstance(scale, RowMod) or isinstance(shift, RowMod):
+    per_token = isinstance(scale, RowMod) or isinstance(shift, RowMod)
+    if per_token:
         if not (isinstance(scale, RowMod) and isinstance(shift, RowMod)):
             raise Lx2vError("ln_modulate: scale and shift must both be per-token (RowMod) or both vectors")
         sc, sc_rows = scale.checked("scale", rows, dim, x)
         sh, sh_rows = shift.checked("shift", rows, dim, x)
         if sc_rows.stride(0) != sh_rows.stride(0):
             raise Lx2vError("ln_modulate: per-token scale and shift rows must share one row stride")
+    if quant:
+        if out is not None:
+            raise Lx2vError("ln_modulate: `out` and `quant` exclude each other")
+        if not per_token:
+            sc, sh, sc_rows, sh_rows = _vec_f32("scale", scale, dim, x), _vec_f32("shift", shift, dim, x), None, None
+        q = torch.empty((rows, dim), dtype=torch.float8_e4m3fn, device=x.device)
+        qs = torch.empty((rows,), dtype=torch.float32, device=x.device)
+        st = load().lx2v_ln_modulate_quant_fp8(x.data_ptr(), x.stride(0), _ptr(w), _ptr(b), _ptr(sc), _ptr(sh), _ptr(sc_rows), _ptr(sh_rows),
+                                                0 if sc_rows is None else sc_rows.stride(0), q.data_ptr(), q.stride(0), qs.data_ptr(), rows, dim, eps, _stream())
+        _check(st, "lx2v_ln_modulate_quant_fp8")
+        return QuantRows(q, qs)
+    if out is None:
+        out = torch.empty((rows, dim), dtype=x.dtype, device=x.device)
+    else:
+        _need_out("ln_modulate.out", out, (rows, dim), x)
+    if per_token:
         st = load().lx2v_ln_modulate_rows_bf16(x.data_ptr(), x.stride(0), _ptr(w), _ptr(b), _ptr(sc), _ptr(sh), sc_rows.data_ptr(), sh_rows.data_ptr(),
                                                 sc_rows.stride(0), out.data_ptr(), out.stride(0), rows, dim, eps, _stream())
         _check(st, "lx2v_ln_modulate_rows_bf16")

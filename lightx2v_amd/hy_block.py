@@ -228,7 +228,7 @@ class HunyuanVideo15TransformerInfer:
         """LN + modulate, q|k|v projections into `qkv_rows` [rows, 3D], per-head RMSNorm of q and k
         (+ RoPE when a table is given), all in place (transformer_infer.py:153-216)."""
         D = x.shape[1]
-        y = b.part("norm1").apply_modulate(x, mod[1], mod[0])
+        y = b.part("norm1").apply_modulate(x, mod[1], mod[0], quant_for=b.fused_qkv() if self.fused_block else None)
         if self.fused_block:
             b.fused_qkv().apply(y, out=qkv_rows)
         else:
@@ -253,7 +253,7 @@ class HunyuanVideo15TransformerInfer:
         (transformer_infer.py:252-270)."""
         if self.fused_block:
             b.part("attn_proj").apply_residual_(attn_rows, x, mod[2])
-            h = b.part("mlp_fc1").apply_gelu(b.part("norm2").apply_modulate(x, mod[4], mod[3]))
+            h = b.part("mlp_fc1").apply_gelu(b.part("norm2").apply_modulate(x, mod[4], mod[3], quant_for=b.part("mlp_fc1")))
             b.part("mlp_fc2").apply_residual_(h, x, mod[5])
         else:
             hip.gate_residual_(x, b.part("attn_proj").apply(attn_rows), mod[2])

@@ -173,6 +173,7 @@ class HipMMWeight:
         self.config = config
 
     supports_kseg = True  # apply_residual_ can read a K-segmented A operand
+    accepts_quantized = False  # input_tensor may be hip.QuantRows (e4m3 rows + per-row scales)
 
     def adopt(self, weight_nk: torch.Tensor, bias: Optional[torch.Tensor]):
         """Use existing storage (e.g. a slice of a fused q|k|v weight) instead of copying."""
@@ -308,6 +309,7 @@ class HipFp8MMWeight(HipMMWeight):
         raise NotImplementedError("hip-fp8: block-streamed (offload) loading is not built")
 
     supports_kseg = False  # the activation is re-quantised row by row, which needs whole rows
+    accepts_quantized = True  # a producer that holds whole rows (LayerNorm) may hand over hip.QuantRows
 
     def adopt(self, weight_nk, bias, weight_scale=None):
         if weight_scale is None:
@@ -329,7 +331,7 @@ class HipFp8MMWeight(HipMMWeight):
         return out
 
     def _run(self, x, epilogue, resid=None, gate=None, out=None):
-        xq, xs = hip.quant_fp8_rowwise(x)
+        xq, xs = (x.q, x.scale) if isinstance(x, hip.QuantRows) else hip.quant_fp8_rowwise(x)
         return hip.gemm_fp8(xq, xs, self.weight_nk, self.weight_scale, self.bias, epilogue=epilogue, resid=resid, gate=gate,
                             out=resid if epilogue == hip.EPI_RESIDUAL else out)
 
@@ -348,6 +350,14 @@ class HipFp8MMWeight(HipMMWeight):
 
 
 # ----------------------------------------------------------------------------------- norms
+def _all_take_quantized(consumers) -> bool:
+    if consumers is None:
+        return False
+    if not isinstance(consumers, (list, tuple)):
+        consumers = (consumers,)
+    return len(consumers) > 0 and all(getattr(c, "accepts_quantized", False) for c in consumers)
+
+
 class _NormBase:
     def __init__(self, create_cuda_buffer, lazy_load, lazy_load_file, is_post_adapter, eps):
         self.create_cuda_buffer = create_cuda_buffer
@@ -420,12 +430,14 @@ class HipLNWeight(_NormBase):
         if self.bias_name is not None and self.weight is not None:
             self.bias = destination.get(_renumber(self.bias_name, idx))
 
-    def apply(self, input_tensor):
-        return hip.ln_modulate(input_tensor, self.weight, self.bias, eps=self.eps)
+    def apply(self, input_tensor, quant_for=None):
+        """`quant_for`: the matmul plugin(s) that alone consume the result; when they all take
+        quantised rows (`accepts_quantized`), the result leaves the kernel as hip.QuantRows."""
+        return hip.ln_modulate(input_tensor, self.weight, self.bias, eps=self.eps, quant=_all_take_quantized(quant_for))
 
-    def apply_modulate(self, input_tensor, scale, shift):
+    def apply_modulate(self, input_tensor, scale, shift, quant_for=None):
         """LN fused with `x * (1 + scale) + shift` (transformer_infer.py:12-13,154-157)."""
-        return hip.ln_modulate(input_tensor, self.weight, self.bias, scale, shift, eps=self.eps)
+        return hip.ln_modulate(input_tensor, self.weight, self.bias, scale, shift, eps=self.eps, quant=_all_take_quantized(quant_for))
 
 
 @RMS_WEIGHT_REGISTER("hip")

@@ -252,7 +252,7 @@ class WanTransformerInfer:
         H, d = self.num_heads, self.head_dim
         rope_in_attn = self.rope_type == "hip_attn"
         if self.fused_block:
-            norm1_out = phase.norm1.apply_modulate(x, scale_msa, shift_msa)
+            norm1_out = phase.norm1.apply_modulate(x, scale_msa, shift_msa, quant_for=phase.fused_qkv())  # e4m3 rows for a W8A8 projection
             qkv = phase.fused_qkv().apply(norm1_out)  # [S, 3D]
             q2, k2, v2 = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
             table = None if rope_in_attn else self.cos_sin
@@ -301,7 +301,7 @@ class WanTransformerInfer:
             context_img = None
         if self.fused_block:
             # (the gated self-attention residual was already added by infer_self_attn)
-            norm3_out = phase.norm3.apply(x)
+            norm3_out = phase.norm3.apply(x, quant_for=phase.cross_attn_q)
             q2 = phase.cross_attn_q.apply(norm3_out)
             phase.cross_attn_norm_q.apply_(q2)
             kv = phase.fused_kv().apply(context)  # [T, 2D]
@@ -331,7 +331,7 @@ class WanTransformerInfer:
     def infer_ffn(self, phase, x, attn_out, c_shift_msa, c_scale_msa, c_gate_msa=None):
         if not self.fused_block:
             hip.gate_residual_(x, attn_out, None)
-        norm2_out = phase.norm2.apply_modulate(x, c_scale_msa, c_shift_msa)
+        norm2_out = phase.norm2.apply_modulate(x, c_scale_msa, c_shift_msa, quant_for=phase.ffn_0 if self.fused_block else None)
         if self.fused_block:
             hmid = phase.ffn_0.apply_gelu(norm2_out)
             phase.ffn_2.apply_residual_(hmid, x, c_gate_msa)  # x += (h W2^T + b) * c_gate

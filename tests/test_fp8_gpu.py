@@ -133,3 +133,66 @@ def test_block_with_fp8_linears(cuda, fused):
     c_out, c_delta = cos(out, ref), cos(out.float().cpu() - c["x"], ref - c["x"])
     print(f"\nfp8 block: output cosine {c_out:.6f}, delta cosine {c_delta:.6f}")
     assert c_out >= 0.999 and c_delta >= 0.99
+
+
+@pytest.mark.parametrize("rows,dim", [(1, 128), (37, 1536), (130, 2048), (21, 5120), (9, 8192)])
+@pytest.mark.parametrize("mode", ["plain", "affine", "modulated", "per_token"])
+def test_ln_modulate_quantised_output_is_the_quantised_bf16_output(cuda, rows, dim, mode):
+    """The LayerNorm that hands e4m3 rows + row scales to a W8A8 Linear: byte for byte what
+    quantising its bf16 output gives (and so, through the bit-exact quantisation test above, what the
+    restated reference formula gives for that output)."""
+    g = torch.Generator().manual_seed(rows * 31 + dim)
+    x = (torch.randn(rows, dim, generator=g) * 3 + 0.5).to(torch.bfloat16).to(cuda)
+    ln_w = ln_b = scale = shift = None
+    if mode == "affine":
+        ln_w, ln_b = (1 + 0.1 * torch.randn(dim, generator=g)).to(cuda), (0.1 * torch.randn(dim, generator=g)).to(cuda)
+    if mode in ("modulated", "per_token"):
+        scale, shift = (0.3 * torch.randn(dim, generator=g)).to(cuda), (0.3 * torch.randn(dim, generator=g)).to(cuda)
+    if mode == "per_token":
+        rows6 = (0.2 * torch.randn(rows, 6 * dim, generator=g)).to(torch.bfloat16).to(cuda)
+        scale, shift = hip.RowMod(scale, rows6[:, dim:2 * dim]), hip.RowMod(shift, rows6[:, :dim])
+    plain = hip.ln_modulate(x, ln_w, ln_b, scale, shift)
+    q_ref, s_ref = hip.quant_fp8_rowwise(plain)
+    got = hip.ln_modulate(x, ln_w, ln_b, scale, shift, quant=True)
+    assert isinstance(got, hip.QuantRows) and got.q.dtype == torch.float8_e4m3fn and tuple(got.shape) == (rows, dim)
+    assert torch.equal(got.scale, s_ref)
+    assert torch.equal(got.q.view(torch.uint8), q_ref.view(torch.uint8))
+    with pytest.raises(hip.Lx2vError):
+        hip.ln_modulate(x, ln_w, ln_b, scale, shift, quant=True, out=plain)
+
+
+def test_fp8_block_is_unchanged_by_quantising_inside_the_layernorm(cuda, monkeypatch):
+    """The fused runner lets the three LayerNorms quantise for their W8A8 consumers; the block
+    output is bit-identical to the one with separate quantisation passes, and the LayerNorms really
+    hand over quantised rows."""
+    rec = load_golden("wan1p3b_g3x6x8")
+    c = case_inputs(rec)
+    cfg = {"num_layers": 1, "num_heads": c["heads"], "dim": c["dim"], "task": "t2v", "dit_quant_scheme": "hip-fp8", "fused_block": True}
+    W = L.WanTransformerWeights(cfg)
+    W.load({k: v.to(cuda) for k, v in {**c["w"], **c["hw"]}.items()})
+    W.to_cuda()
+    inf = L.WanTransformerInfer(cfg)
+    inf.cos_sin = R.cos_sin_to_real(c["cos_sin"]).contiguous().to(cuda)
+    inf.get_scheduler_values = lambda: None
+
+    def run():
+        pre = L.WanPreInferModuleOutput(embed=c["embed"].to(cuda), grid_sizes=c["grid"], x=c["x"].to(torch.bfloat16).to(cuda),
+                                        embed0=c["embed0"].to(cuda), context=c["context"].to(torch.bfloat16).to(cuda))
+        return inf.infer_main_blocks(W.blocks, pre).clone()
+
+    seen = []
+    real = hip.ln_modulate
+
+    def spy(*a, **k):
+        out = real(*a, **k)
+        seen.append(type(out).__name__)
+        return out
+
+    monkeypatch.setattr(hip, "ln_modulate", spy)
+    folded = run()
+    assert seen == ["QuantRows"] * 3
+    monkeypatch.setattr(L.MM_WEIGHT_REGISTER["hip-fp8"], "accepts_quantized", False)
+    seen.clear()
+    separate = run()
+    assert seen == ["Tensor"] * 3
+    assert torch.equal(folded, separate)

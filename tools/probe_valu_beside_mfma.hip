@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k(const u32x4* in, float* out, int iters,
   for (int i = 0; i < 8; ++i) r += e[i];
   out[blockIdx.x * 256 + threadIdx.x] = r;
 }
-// gap pattern: eight masks (1 exp, 2 add, 4 convert, 8 = exp issued last, 16 = a second add, 32 = a ds_read_b128 directly behind the MFMA, 64 = a second one, 128 = s_waitcnt lgkmcnt(8), 256 = s_add_u32 m0), repeated over the 64 gaps
+// gap pattern: eight masks (512 = v_dot2c_f32_bf16 of the pair converted in the previous gap with a ones pair, 1024 = the same on the pair converted four gaps ago, 2048 = the VOP3P form v_dot2_f32_bf16 of 512; 1 exp, 2 add, 4 convert, 8 = exp issued last, 16 = a second add, 32 = a ds_read_b128 directly behind the MFMA, 64 = a second one, 128 = s_waitcnt lgkmcnt(8), 256 = s_add_u32 m0), repeated over the 64 gaps
 template <int M0, int M1, int M2, int M3, int M4 = M0, int M5 = M1, int M6 = M2, int M7 = M3>
 __global__ __launch_bounds__(256) void kp(const u32x4* in, float* out, int iters, long long* cyc) {
   const int lane = threadIdx.x & 63;
@@ -50,6 +50,8 @@ __global__ __launch_bounds__(256) void kp(const u32x4* in, float* out, int iters
   for (int i = 0; i < 8; ++i) { a[i] = in[(i * 64 + lane) & 4095]; b[i] = in[(i * 64 + lane + 1024) & 4095]; }
   float x[8], e[8], acc[4] = {0.f, 0.f, 0.f, 0.f};
   unsigned pk[8] = {};
+  unsigned ones = 0x3f803f80u;
+  asm volatile("" : "+v"(ones));
   for (int i = 0; i < 8; ++i) { x[i] = -0.01f * (lane + i); e[i] = 0.f; }
   f32x4 c16[8] = {};
   __shared__ u32x4 lds[1024];
@@ -72,6 +74,9 @@ __global__ __launch_bounds__(256) void kp(const u32x4* in, float* out, int iters
       if constexpr (M & 2) asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc[j & 3]) : "v"(e[(j + 4) & 7]));
       if constexpr (M & 16) asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc[(j + 1) & 3]) : "v"(e[(j + 6) & 7]));
       if constexpr (M & 4) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[j & 7]) : "v"(e[(j + 3) & 7]), "v"(e[(j + 5) & 7]));
+      if constexpr (M & 512) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc[j & 3]) : "v"(pk[(j + 7) & 7]), "v"(ones));
+      if constexpr (M & 1024) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc[j & 3]) : "v"(pk[(j + 4) & 7]), "v"(ones));
+      if constexpr (M & 2048) asm volatile("v_dot2_f32_bf16 %0, %1, %2, %0" : "+v"(acc[j & 3]) : "v"(pk[(j + 7) & 7]), "v"(ones));
       if constexpr ((M & 1) && (M & 8)) asm volatile("v_exp_f32 %0, %1" : "=v"(e[j & 7]) : "v"(x[j & 7]));
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -140,6 +145,16 @@ int main() {
   runp(kp<257, 1, 6, 2>, "ME | E | AC | A");
   runp(kp<1, 1, 6, 258>, "E | E | AC | MA");
   runp(kp<1, 1, 6, 34, 1, 1, 6, 34>, "E | E | AC | RA (x2)");
+  runp(kp<1, 1, 4, 512>, "E | E | C | D");
+  runp(kp<1, 1, 4, 2048>, "E | E | C | D(vop3p)");
+  runp(kp<1, 1, 4 | 1024, 0>, "E | E | CD | -");
+  runp(kp<1, 4 | 1024, 1, 0>, "E | CD | E | -");
+  runp(kp<1, 1, 4, 512 | 32>, "E | E | C | RD");
+  runp(kp<1, 1, 4 | 1024, 32>, "E | E | CD | R");
+  runp(kp<1, 1, 4 | 1024, 32 | 64>, "E | E | CD | RR");
+  runp(kp<1, 1, 4 | 1024, 32 | 256>, "E | E | CD | RM");
+  runp(kp<1, 1, 4 | 1024, 32, 1, 1, 4 | 1024, 0>, "E | E | CD | R | E | E | CD | -");
+  runp(kp<1, 1, 6, 34, 1, 1, 6, 2>, "E | E | AC | RA | E | E | AC | A (present)");
   runp(kp<32, 0, 0, 0>, "R | - | - | -");
   runp(kp<32, 32, 32, 32>, "R | R | R | R");
   return 0;
