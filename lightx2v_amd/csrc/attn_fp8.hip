@@ -26,17 +26,14 @@
 // double-buffered in LDS, tile t+1 is in flight while tile t is consumed.
 #include <mutex>
 
-#include "attn_common.h"
+#include "attn_fp8_common.h"
 
 using namespace lx2v_attn;
+using namespace lx2v_attn_fp8;
 
 namespace {
 
-typedef int i32x8 __attribute__((ext_vector_type(8)));
-
-constexpr int K_DATA = 0, K_SCALE = 8192, V_DATA = 8704, V_SCALE = 16896, TILE_BLOB = 17152;
 constexpr int PAIR_BLOB = 2 * TILE_BLOB;  // staging unit: two consecutive tiles (one barrier per unit)
-constexpr int UNIT_SCALE = 127;  // E8M0 byte of 2^0
 
 // Smallest power of two 2^e with amax / 2^e <= 448 (the e4m3 maximum), from the bits of amax:
 // 448 = 1.75 * 2^8, so e = exponent(amax) - 8, one more when the mantissa exceeds 1.75.  Returns the
@@ -136,15 +133,6 @@ __global__ __launch_bounds__(128) void mxq_v_kernel(const uint16_t* __restrict__
       *reinterpret_cast<u32x4*>(blob + V_DATA + d * 64 + ((chunk ^ ((d >> 2) & 3)) << 4)) = u32x4{lo[0], lo[1], hi[0], hi[1]};
     }
 }
-
-struct Fp8AttnParams {
-  const uint8_t* q8;       // [sq][heads][128]
-  const uint8_t* qs;       // [sq][heads][4]
-  const uint8_t* kv;       // [heads][tiles][TILE_BLOB]
-  uint16_t* out;
-  int64_t ldo;
-  int sq, skv, heads, nqb, tiles;
-};
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
@@ -423,6 +411,7 @@ static int attn_fwd_fp8_on(const uint16_t* q, int64_t ldq, const uint16_t* k, in
   p.nqb = (int)((sq + QROWS - 1) / QROWS);
   const int64_t nwg = (int64_t)p.nqb * heads;
   LX2V_REQUIRE(nwg < (1LL << 31), LX2V_EUNSUP, "attn_fwd_fp8: grid too large");
+  if (lx2v_options().attn_fp8_kernel != 8) return lx2v_attn_fp8_launch_w4(p, st);
   if (skv <= 2048) hipLaunchKernelGGL(attn_fwd_fp8_kernel<true>, dim3((unsigned)nwg), dim3(NTHREADS), 0, st, p);
   else hipLaunchKernelGGL(attn_fwd_fp8_kernel<false>, dim3((unsigned)nwg), dim3(NTHREADS), 0, st, p);
   LX2V_CHECK_LAUNCH("attn_fwd_fp8");

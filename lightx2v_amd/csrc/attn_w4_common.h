@@ -76,10 +76,18 @@ struct RoundHost {
 };
 
 // Launch `kshort` (skv <= 2048) or `klong` over the first `nwg` of the nqb * heads workgroups
-// (head-major order) with `threads` threads each, with round alignment when a head's K/V outgrows
-// an XCD's L2 (4 MiB) and there are many rounds.
+// (head-major order) with `threads` threads each, with round alignment when a head's K/V
+// (`kv_bytes_per_head` as staged) outgrows an XCD's L2 (4 MiB) and there are many rounds.
+template <class KS, class KL, class P>
+int launch_with_rounds(KS kshort, KL klong, int threads, const P& p, int64_t kv_bytes_per_head, int64_t nwg, hipStream_t st, const char* what);
+
 template <class KS, class KL>
 int launch_with_rounds(KS kshort, KL klong, int threads, const lx2v_attn::AttnParams& p, int64_t nwg, hipStream_t st, const char* what) {
+  return launch_with_rounds(kshort, klong, threads, p, (int64_t)p.skv * lx2v_attn::HD * 4, nwg, st, what);
+}
+
+template <class KS, class KL, class P>
+int launch_with_rounds(KS kshort, KL klong, int threads, const P& p, int64_t kv_bytes_per_head, int64_t nwg, hipStream_t st, const char* what) {
   RoundSync rs{};
   rs.done = nullptr;
   rs.cus_per_xcd = 32;
@@ -87,7 +95,7 @@ int launch_with_rounds(KS kshort, KL klong, int threads, const lx2v_attn::AttnPa
   static RoundHost host[64];
   RoundHost* h = nullptr;
   unsigned slot = 0;
-  if (lx2v_options().attn_round_sync != 0 && (int64_t)p.skv * lx2v_attn::HD * 4 > (8 << 20)) {
+  if (lx2v_options().attn_round_sync != 0 && kv_bytes_per_head > (8 << 20)) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { lx2v_set_error("%s: hipGetDevice failed", what); return LX2V_EHIP; }
     std::lock_guard<std::mutex> lock(mu);

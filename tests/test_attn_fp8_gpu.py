@@ -49,6 +49,27 @@ def test_fp8_attention_matches_fp32_softmax_and_emulation(cuda, sq, skv, H):
     assert cos(out, emu) >= 0.999
 
 
+@pytest.mark.parametrize("sq,skv,H", [(64, 64, 1), (257, 512, 3), (1000, 1000, 2), (96, 77, 2), (300, 1700, 1)])
+def test_fp8_attention_kernels_agree(cuda, sq, skv, H):
+    """The one-wave-per-SIMD kernel (default) and the 8-wave kernel compute the same thing from the
+    same quantised operands, but a wave of the former holds 64 query rows and of the latter 32, and
+    a wave moves the running maxima of all its rows when one of them calls for it: the per-row
+    offset under which P is rounded to e4m3 differs between the two, so they agree to the rounding
+    noise of P (the figure both show against the emulation), not bit for bit."""
+    q, k, v = (t.to(cuda) for t in _qkv(sq, skv, H, 900 + skv, spread=1.5))
+    assert hip.get_option("attn_fp8_kernel") == 4
+    a = hip.attn_fwd_fp8(q, k, v).float()
+    hip.set_option("attn_fp8_kernel", 8)
+    try:
+        b = hip.attn_fwd_fp8(q, k, v).float()
+    finally:
+        hip.set_option("attn_fp8_kernel", 4)
+    assert torch.isfinite(a).all()
+    rel_rms = ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
+    print(f"\nfp8 kernels sq={sq} skv={skv} H={H}: cos {cos(a.cpu(), b.cpu()):.6f}, rel rms {rel_rms:.4f}")
+    assert cos(a.cpu(), b.cpu()) >= 0.9993 and rel_rms <= 0.04
+
+
 def test_fp8_attention_peaked_scores_and_strided_inputs(cuda):
     """Large score spread (the online-softmax rescale path runs) with q, k, v as thirds of one
     [S, 3*H*128] buffer (the fused block's layout)."""
