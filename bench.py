@@ -243,13 +243,13 @@ def run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu):
     if H % seq_p != 0:
         raise SystemExit(f"heads_num={H} not divisible by seq_p={seq_p}")
     seq_group = None
-    if world > 1:
+    if world > 1 or args.sp1:
         _, _, seq_group, _ = ulysses.make_groups(1, seq_p)
     C, TEXT_DIM, TXT_TOKENS, BYT5_TOKENS, VIS_TOKENS = 32, 3584, 1000, 256, 729
     cfg = {"mm_double_blocks_depth": layers, "heads_num": H, "hidden_size": D, "task": "t2v", "patch_size": (1, 1, 1), "out_channels": C,
            "dit_quant_scheme": "hip-bf16" if args.linear == "bf16" else "hip-fp8",
            "attn_type": "hip_flash_attn" if args.attn == "bf16" else "hip_fp8_attn",
-           "seq_parallel": seq_p > 1, "seq_p_group": seq_group, "parallel": {"seq_p_size": seq_p, "seq_p_attn_type": "hip_ulysses"},
+           "seq_parallel": seq_p > 1 or args.sp1, "seq_p_group": seq_group, "parallel": {"seq_p_size": seq_p, "seq_p_attn_type": "hip_ulysses"},
            "enable_cfg": False, "sample_guide_scale": -1.0, "sample_shift": 5.0, "infer_steps": 4, "denoising_step_list": [1000, 750, 500, 250],
            "rope_dim_list": [16, 56, 56], "rope_theta": 256.0, "run_device": str(dev)}
     model = L.HunyuanVideo15Model(cfg)
@@ -325,7 +325,7 @@ def run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu):
         step()
     for t in timers:
         t.enabled = True
-    if world > 1:
+    if world > 1 or args.sp1:
         ulysses.COMM_TIMER.enable()
     fence()
     t0 = time.perf_counter()
@@ -338,7 +338,7 @@ def run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert torch.isfinite(out.float()).all()
-    exposed_ms = ulysses.COMM_TIMER.total_ms() / args.steps if world > 1 else 0.0
+    exposed_ms = ulysses.COMM_TIMER.total_ms() / args.steps if (world > 1 or args.sp1) else 0.0
     s_per_step = elapsed / args.steps
     n_launches = sum(len(t.events) for t in timers)
     attn_ms = sum(t.total_ms() for t in timers) / max(1, n_launches)
@@ -353,12 +353,14 @@ def run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu):
         "ms_per_step": s_per_step * 1e3, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
         "dtype": arithmetic_label(args)[0],
         "data": "synthetic latents, text / glyph / image-encoder features and masks, random-init weights of the named architecture"
-                + ("" if (backend == "nccl" and not share_gpu) else f" [REHEARSAL: backend={backend} share_gpu={share_gpu}, not a measurement]"),
+                + ("" if (backend == "nccl" and not share_gpu) else f" [REHEARSAL: backend={backend} share_gpu={share_gpu}, not a measurement]")
+                + (" [--sp1: sequence-parallel code path on an RCCL group of one rank]" if args.sp1 else ""),
         "config": {"workload": f"{args.model} {args.res} x{frames}f: {S} image + {HY_TEXT_LEN} text tokens, full denoise step (pre-infer with token refiner, {layers} double-stream blocks + final layer, unpatchify, distilled-schedule update), no CFG",
                    "parallelism": f"seq_p{seq_p} (ulysses)", "tokens": S, "dim": D, "heads": H, "ffn_dim": F, "layers": layers},
         "step_tflops": step_flops / 1e12, "achieved_tflops_per_gpu": step_flops / s_per_step / 1e12 / world,
-        "exposed_comm_ms_per_step": exposed_ms, "ulysses_chunks": int(os.environ.get("LX2V_ULYSSES_CHUNKS") or ulysses.default_chunks(seq_p)),
-        "roofline": {"kernel": ("attn_fwd_x16_kernel" if args.attn == "bf16" else "attn_fwd_fp8_kernel<false> + quantisation pre-pass") + " (joint image+text attention)",
+        "exposed_comm_ms_per_step": exposed_ms, "ulysses_chunks": len(ulysses.LAST_WIDTHS) or int(os.environ.get("LX2V_ULYSSES_CHUNKS") or ulysses.default_chunks(seq_p)),
+        "ulysses_chunk_heads": list(ulysses.LAST_WIDTHS),
+        "roofline": {"kernel": ("attn_fwd_x16_kernel" if args.attn == "bf16" else "attn_fwd_fp8_w4_kernel + quantisation pre-pass") + " (joint image+text attention)",
                      "bound": "mfma", "achieved": achieved, "peak": attn_peak(args),
                      "unit": "TFLOP/s", "frac": achieved / attn_peak(args), "traffic": None,
                      "launch_ms": attn_ms, "flops_per_launch": attn_flops, "launches_timed": n_launches},
@@ -379,6 +381,10 @@ def main():
     ap.add_argument("--attn", default="bf16", choices=["bf16", "fp8"],
                     help="self-attention arithmetic: bf16 (the headline configuration) or block-scaled e4m3 on the fp8 MFMA (where the reference would run a quantised backend)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sp1", action="store_true",
+                    help="one GPU only: run the sequence-parallel code path on an RCCL group of ONE rank (pack kernel, chunked attention, "
+                         "asynchronous all-to-alls that move the rank's own data, segmented output projection, final all_gather); "
+                         "prices what the N > 1 path costs besides the links")
     args = ap.parse_args()
 
     if os.environ.get("LX2V_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit after N seconds
@@ -397,7 +403,13 @@ def main():
     dev_index = 0 if share_gpu else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    if args.sp1:
+        if world != 1:
+            raise SystemExit("--sp1 is a one-GPU run")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    elif world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -417,7 +429,7 @@ def main():
         line = run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu)
         if rank == 0:
             print(json.dumps(line), flush=True)
-        if world > 1:
+        if world > 1 or args.sp1:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -432,7 +444,7 @@ def main():
 
     cfg_idx = seq_idx = 0
     seq_group = cfg_group = None
-    if world > 1:
+    if world > 1 or args.sp1:
         cfg_idx, seq_idx, seq_group, cfg_group = ulysses.make_groups(cfg_p, seq_p)
     cfg = {"num_layers": layers, "num_heads": H, "dim": D, "ffn_dim": F, "task": "t2v", "model_cls": "wan2.1",
            "in_dim": LATENT_CHANNELS, "out_dim": LATENT_CHANNELS, "freq_dim": 256, "infer_steps": 50, "sample_shift": 5.0,
@@ -440,7 +452,7 @@ def main():
            "dit_quant_scheme": "hip-bf16" if args.linear == "bf16" else "hip-fp8",
            "self_attn_1_type": "hip_flash_attn" if args.attn == "bf16" else "hip_fp8_attn",
            "cfg_parallel": cfg_p > 1, "cfg_p_group": cfg_group,
-           "seq_parallel": seq_p > 1, "seq_p_group": seq_group, "parallel": {"seq_p_size": seq_p, "cfg_p_size": cfg_p, "seq_p_attn_type": "hip_ulysses"}}
+           "seq_parallel": seq_p > 1 or args.sp1, "seq_p_group": seq_group, "parallel": {"seq_p_size": seq_p, "cfg_p_size": cfg_p, "seq_p_attn_type": "hip_ulysses"}}
     moe = args.model == "wan2.2-i2v-a14b"
     i2v_clip = args.model == "wan2.1-i2v-14b"
     if moe:
@@ -487,7 +499,8 @@ def main():
             picks.append(model.cur_model_index)
         if dbg:
             torch.cuda.synchronize()
-            print(f"[rank {rank}] step {i} done, latents finite={bool(torch.isfinite(sch.latents).all())}", flush=True)
+            print(f"[rank {rank}] step {i} done, latents finite={bool(torch.isfinite(sch.latents).all())} mean|x|={float(sch.latents.abs().mean()):.6f} "
+                  f"mean|pred|={float(sch.noise_pred.abs().mean()):.6f}", flush=True)
         return sch.latents
 
     def fence():
@@ -500,7 +513,7 @@ def main():
         step()
     for t in timers:
         t.enabled = True
-    if world > 1:
+    if world > 1 or args.sp1:
         ulysses.COMM_TIMER.enable()
     fence()
     t0 = time.perf_counter()
@@ -523,14 +536,15 @@ def main():
     step_flops = (sa + ca + ge) * layers * 2
 
     traffic, traffic_source = measured_traffic(S_pad, H // seq_p) if (args.attn == "bf16" and n_launches == layers * 2 * args.steps // cfg_p) else (None, None)
-    exposed_ms = ulysses.COMM_TIMER.total_ms() / args.steps if world > 1 else 0.0
+    exposed_ms = ulysses.COMM_TIMER.total_ms() / args.steps if (world > 1 or args.sp1) else 0.0
     if rank == 0:
         line = {
             "metric": "s/denoise-step Wan2.1-T2V-14B 720p81f" if (args.model, args.res, args.linear, args.attn) == ("wan2.1-t2v-14b", "720p", "bf16", "bf16") else f"s/denoise-step {args.model} {args.res}81f" + arithmetic_label(args)[1],
             "value": s_per_step, "unit": "s/denoise-step", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": s_per_step * 1e3, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
             "dtype": arithmetic_label(args)[0], "data": "synthetic latents and text features, random-init weights of the named architecture"
-                    + ("" if (backend == "nccl" and not share_gpu) else f" [REHEARSAL: backend={backend} share_gpu={share_gpu}, not a measurement]"),
+                    + ("" if (backend == "nccl" and not share_gpu) else f" [REHEARSAL: backend={backend} share_gpu={share_gpu}, not a measurement]")
+                + (" [--sp1: sequence-parallel code path on an RCCL group of one rank]" if args.sp1 else ""),
             "config": {"workload": f"{args.model} {args.res} x81f: {S} tokens, full denoise step (pre-infer, {layers} blocks + head, unpatchify) x 2 CFG forwards + CFG combine + UniPC update, text len {TEXT_LEN}"
                                    + (f"; two resident experts, switch at t = {MOE_BOUNDARY} (experts of the timed steps: {picks[args.warmup:]}), {MOE_COND_CHANNELS} conditioning channels" if moe else "")
                                    + (f"; {CLIP_TOKENS} CLIP image tokens (img_emb MLP + second cross-attention per block), {MOE_COND_CHANNELS} conditioning channels" if i2v_clip else ""),
@@ -538,8 +552,9 @@ def main():
             "step_tflops": step_flops / 1e12,
             "achieved_tflops_per_gpu": step_flops / s_per_step / 1e12 / world,
             # rank 0's compute stream blocked in waits for the Ulysses exchanges, per step (events around each wait)
-            "exposed_comm_ms_per_step": exposed_ms, "ulysses_chunks": int(os.environ.get("LX2V_ULYSSES_CHUNKS") or ulysses.default_chunks(seq_p)),
-            "roofline": {"kernel": "attn_fwd_x16_kernel (self-attention: main launch + 64-row tail launch)" if args.attn == "bf16" else "attn_fwd_fp8_kernel<false> + quantisation pre-pass (self-attention)",
+            "exposed_comm_ms_per_step": exposed_ms, "ulysses_chunks": len(ulysses.LAST_WIDTHS) or int(os.environ.get("LX2V_ULYSSES_CHUNKS") or ulysses.default_chunks(seq_p)),
+        "ulysses_chunk_heads": list(ulysses.LAST_WIDTHS),
+            "roofline": {"kernel": "attn_fwd_x16_kernel (self-attention: main launch + 64-row tail launch)" if args.attn == "bf16" else "attn_fwd_fp8_w4_kernel + quantisation pre-pass (self-attention)",
                          "bound": "mfma", "achieved": achieved, "peak": attn_peak(args),
                          "unit": "TFLOP/s", "frac": achieved / attn_peak(args),
                          "traffic": traffic, "traffic_source": traffic_source,
@@ -549,7 +564,7 @@ def main():
             threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
             line["cpu_baseline"] = cpu_baseline(D, H, F, S, layers, threads)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or args.sp1:
         dist.barrier()
         dist.destroy_process_group()
 

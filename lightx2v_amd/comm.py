@@ -21,12 +21,21 @@ import torch
 import torch.distributed as dist
 
 
+# RCCL 2.26.6 (ROCm 7.0) moves only the first half of a per-peer payload above 1 GiB and reports success
+# (tools/probe_rccl_self_a2a.py: 1024 MiB arrives whole, 1107 MiB arrives as its first 553.5 MiB).
+RCCL_MAX_PEER_BYTES = 1 << 30
+
+
 class DistTransport:
-    """torch.distributed, unchanged."""
+    """torch.distributed, unchanged (plus a refusal of payloads RCCL is known to truncate)."""
 
     name = "torch.distributed"
 
     def all_to_all_single(self, output: torch.Tensor, input: torch.Tensor, group=None, async_op: bool = False):
+        per_peer = input.numel() * input.element_size() // max(1, dist.get_world_size(group))
+        if per_peer > RCCL_MAX_PEER_BYTES and input.is_cuda:
+            raise ValueError(f"all_to_all_single: {per_peer / 2**20:.0f} MiB per peer; RCCL moves payloads above 1024 MiB only in part -- split the exchange "
+                             "(the Ulysses exchange does: LX2V_ULYSSES_MAX_PEER_MB)")
         return dist.all_to_all_single(output, input, group=group, async_op=async_op)
 
     def all_gather(self, outputs: List[torch.Tensor], input: torch.Tensor, group=None, async_op: bool = False):

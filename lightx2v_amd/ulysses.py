@@ -57,6 +57,22 @@ def default_chunks(world: int) -> int:
     return 4 if world == 2 else 2
 
 
+# Largest q|k|v payload one rank hands ONE peer in one all-to-all.  RCCL 2.26.6 (ROCm 7.0) returns from an
+# all_to_all_single whose per-peer payload exceeds 1 GiB with only the first half of it moved and no error
+# (tools/probe_rccl_self_a2a.py); the exchange therefore uses more, narrower head chunks when a chunk would
+# come near that size.  Multi-GPU groups are far below it (14B at 720p: 145 MB per peer and chunk in a group of
+# two); a group of one rank at that size is not (1.16 GB in two chunks).
+MAX_PEER_BYTES = int(os.environ.get("LX2V_ULYSSES_MAX_PEER_MB", "512")) << 20
+
+
+def chunks_for_payload(heads_per_rank: int, chunks: int, rows: int, d: int, elem_bytes: int = 2) -> int:
+    """`chunks`, raised until a chunk's q|k|v payload per peer (`rows` tokens x 3 x heads x d) fits MAX_PEER_BYTES."""
+    c = max(1, min(chunks, heads_per_rank))
+    while c < heads_per_rank and rows * 3 * -(-heads_per_rank // c) * d * elem_bytes > MAX_PEER_BYTES:
+        c += 1
+    return c
+
+
 def split_heads(heads_per_rank: int, chunks: int) -> List[int]:
     """Head-chunk widths of one rank: `chunks` parts as even as the count allows, the wider ones
     first (5 heads in 2 chunks -> [3, 2]); fewer parts when there are fewer heads."""
@@ -110,6 +126,7 @@ class CommTimer:
 
 
 COMM_TIMER = CommTimer()
+LAST_WIDTHS: List[int] = []   # head-chunk widths of the most recent exchange (reporting only)
 
 
 class SegmentedOperand:
@@ -188,7 +205,9 @@ class HipUlyssesAttnWeight(_AttnBase):
         sl, heads, d = q.shape
         if heads % world != 0:
             raise ValueError(f"hip_ulysses: num_heads={heads} is not divisible by the sequence-parallel size {world}")
-        widths = split_heads(heads // world, self.chunks or default_chunks(world))
+        widths = split_heads(heads // world, chunks_for_payload(heads // world, self.chunks or default_chunks(world), sl, d, q.element_size()))
+        global LAST_WIDTHS
+        LAST_WIDTHS = list(widths)
         dim = heads * d
         lt = 0 if txt is None else txt[0].shape[0]
         dev, dt = q.device, q.dtype

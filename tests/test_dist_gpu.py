@@ -55,6 +55,25 @@ def _init(rank, world, port):
     return torch.device("cuda:0")
 
 
+def _init_rccl(port):
+    """A process group of ONE rank on RCCL (backend "nccl" is RCCL on ROCm) with the production
+    transport: every collective of the exchange -- asynchronous all-to-alls on RCCL's own stream,
+    the waits on the compute stream, list-output all_gathers -- goes through the library that
+    carries them on a multi-GPU node, moving this rank's own data."""
+    import faulthandler
+
+    faulthandler.dump_traceback_later(130, exit=True)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from lightx2v_amd import comm
+
+    assert comm.transport().name == "torch.distributed"
+    return dev
+
+
 def _finish():
     import faulthandler
 
@@ -67,8 +86,8 @@ def _finish():
 H10_CASE = {"grid": (3, 5, 7), "dim": 1280, "heads": 10, "ffn": 2560, "text_len": 77, "seed": 11}  # 5 heads per rank of 2: chunks of 3 + 2
 
 
-def _worker(rank, world, port, out_dir, fused, fp8_comm=False, case=None):
-    dev = _init(rank, world, port)
+def _worker(rank, world, port, out_dir, fused, fp8_comm=False, case=None, rccl=False):
+    dev = _init_rccl(port) if rccl else _init(rank, world, port)
     import lightx2v_amd as L
     from lightx2v_amd import ulysses
     from oracle import wan_block_ref as R
@@ -164,8 +183,8 @@ def test_sequence_parallel_block_fp8_payload(cuda, tmp_path, fused):
     assert cos(got8 - c["x"], ref - c["x"]) >= 0.99
 
 
-def _hy_worker(rank, world, port, out_dir):
-    dev = _init(rank, world, port)
+def _hy_worker(rank, world, port, out_dir, rccl=False):
+    dev = _init_rccl(port) if rccl else _init(rank, world, port)
     import lightx2v_amd as L
     from lightx2v_amd import ulysses
     from tests.test_hy_oracle import hy_case_inputs
@@ -208,9 +227,9 @@ def test_hunyuan_double_blocks_sequence_parallel_two_ranks_one_gpu(cuda, tmp_pat
 
 
 # ---- WanModel.infer with cfg_parallel / seq_parallel (lightx2v/models/networks/wan/model.py:412-433,468-499) ----
-def _model_worker(rank, world, port, out_dir, cfg_p, seq_p, chunks):
+def _model_worker(rank, world, port, out_dir, cfg_p, seq_p, chunks, rccl=False):
     os.environ["LX2V_ULYSSES_CHUNKS"] = str(chunks)
-    dev = _init(rank, world, port)
+    dev = _init_rccl(port) if rccl else _init(rank, world, port)
     import lightx2v_amd as L
     from lightx2v_amd import ulysses
     from tests.test_step_oracle import step_case
@@ -220,7 +239,7 @@ def _model_worker(rank, world, port, out_dir, cfg_p, seq_p, chunks):
     cfg = {"dim": meta["dim"], "num_heads": meta["heads"], "num_layers": meta["layers"], "ffn_dim": meta["ffn"], "in_dim": 16, "out_dim": 16,
            "freq_dim": 256, "task": "t2v", "infer_steps": meta["steps"], "sample_shift": meta["shift"], "sample_guide_scale": meta["guide"],
            "enable_cfg": True, "run_device": "cuda", "keep_latents_dtype_in_scheduler": True,
-           "cfg_parallel": cfg_p > 1, "cfg_p_group": cfg_group, "seq_parallel": seq_p > 1, "seq_p_group": seq_group,
+           "cfg_parallel": cfg_p > 1, "cfg_p_group": cfg_group, "seq_parallel": seq_p > 1 or rccl, "seq_p_group": seq_group,
            "parallel": {"seq_p_size": seq_p, "cfg_p_size": cfg_p, "seq_p_attn_type": "hip_ulysses"}}
     m = L.WanModel(cfg, weight_dict=dict(model))
     m.to_cuda()
@@ -302,3 +321,85 @@ def test_hunyuan_model_infer_with_cfg_and_sequence_parallel_groups(cuda, tmp_pat
             assert cos(res[r]["preds"][i], gold) >= 0.999, (i, r, cos(res[r]["preds"][i], gold))
             assert torch.equal(res[r]["preds"][i], res[0]["preds"][i]), (i, r)
     assert cos(res[0]["latents"], torch.from_numpy(np.asarray(rec["latents_2"]))) >= 0.9995
+
+
+# ---- the same paths over RCCL (one rank: the one-GPU box cannot hold two) ----
+@pytest.mark.parametrize("fused,fp8_comm", [(True, False), (False, False), (True, True)])
+def test_sequence_parallel_block_over_rccl_one_rank(cuda, tmp_path, fused, fp8_comm):
+    """The block with `seq_parallel` on a sequence group of one rank whose collectives are RCCL's:
+    the head chunks (the one rank's 10 heads in chunks of 5 and 5), the asynchronous all-to-alls,
+    their waits and the segmented output projection run against the production transport.  A group of one pads nothing, so the result is the unsharded block's."""
+    from oracle import wan_block_ref as R
+    from tests.util import case_inputs, cos
+
+    _spawn(_worker, lambda port: (1, port, str(tmp_path), fused, fp8_comm, H10_CASE, True), 1)
+    c = case_inputs(H10_CASE)
+    got = torch.load(os.path.join(str(tmp_path), f"o0_{int(fused)}{'_fp8' if fp8_comm else ''}.pt"))
+    ref = R.block_forward(c["x"], c["embed0"], c["context"], c["w"], c["cos_sin"], c["heads"])
+    assert got.shape == ref.shape
+    assert cos(got, ref) >= 0.9999
+    assert cos(got - c["x"], ref - c["x"]) >= (0.99 if fp8_comm else 0.995)
+
+
+def test_model_infer_over_rccl_one_rank(cuda, tmp_path):
+    """`WanModel.infer` with `seq_parallel` on an RCCL group of one rank: pad / chunk, Ulysses in every
+    block and the final all_gather on the production transport, against the golden trajectory."""
+    import numpy as np
+    from tests.test_step_oracle import step_case
+    from tests.util import cos
+
+    _spawn(_model_worker, lambda port: (1, port, str(tmp_path), 1, 1, 3, True), 1)
+    rec, meta, _ = step_case("step_small_d512")
+    res = torch.load(os.path.join(str(tmp_path), "m0.pt"))
+    for i in range(2):
+        gold = torch.from_numpy(np.asarray(rec[f"noise_pred_{i}"]))
+        assert cos(res["preds"][i], gold) >= 0.999, (i, cos(res["preds"][i], gold))
+    assert cos(res["latents"], torch.from_numpy(np.asarray(rec["latents_2"]))) >= 0.9995
+
+
+def test_hunyuan_double_blocks_over_rccl_one_rank(cuda, tmp_path):
+    """The HunyuanVideo layout (image rows exchanged, text rows gathered along the head axis with a
+    list-output all_gather) on an RCCL group of one rank, against the reference's unsharded run."""
+    from tests.util import cos, load_golden
+
+    _spawn(_hy_worker, lambda port: (1, port, str(tmp_path), True), 1)
+    res = torch.load(os.path.join(str(tmp_path), "hy0.pt"))
+    rec = load_golden("hy_tiny_d256")
+    assert cos(res["final"][0], torch.from_numpy(rec["final_out"])) >= 0.9995
+
+
+def _full_size_worker(rank, world, port, out_dir):
+    dev = _init_rccl(port)
+    from lightx2v_amd import comm, ulysses
+    from lightx2v_amd.registry_factory import ATTN_WEIGHT_REGISTER
+
+    S, H, d = 75600, 40, 128
+    g = torch.Generator(device=dev).manual_seed(0)
+    q, k, v = (torch.randn(S, H, d, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16) for _ in range(3))
+    plain, uly = ATTN_WEIGHT_REGISTER["hip_flash_attn"](), ATTN_WEIGHT_REGISTER["hip_ulysses"]()
+    group = dist.new_group(ranks=[0])
+    ref = plain.apply(q, k, v, cu_seqlens_q=None, cu_seqlens_kv=None, max_seqlen_q=S, max_seqlen_kv=S)
+    got = uly.apply(q, k, v, img_qkv_len=S, cu_seqlens_qkv=[0, S], attention_module=plain, seq_p_group=group)
+    torch.cuda.synchronize()
+    refused = False
+    big = torch.empty((1 << 30) + 4096, dtype=torch.uint8, device=dev)
+    try:
+        comm.transport().all_to_all_single(torch.empty_like(big), big, group=group)
+    except ValueError:
+        refused = True
+    torch.save({"max_diff": float((got.float() - ref.float()).abs().max()), "max_ref": float(ref.float().abs().max()),
+                "widths": list(ulysses.LAST_WIDTHS), "refused": refused}, os.path.join(out_dir, "full.pt"))
+    _finish()
+
+
+def test_full_size_exchange_over_rccl_one_rank(cuda, tmp_path):
+    """75 600 tokens x 40 heads through the exchange on an RCCL group of one rank: 2.3 GB of q|k|v, which
+    two head chunks would hand RCCL as 1.16 GB per peer -- a size it moves only in part (the first half
+    arrives, no error).  The exchange must split into chunks below the limit and return the plain
+    attention's result; the transport must refuse a payload above 1 GiB outright."""
+    _spawn(_full_size_worker, lambda port: (1, port, str(tmp_path)), 1)
+    res = torch.load(os.path.join(str(tmp_path), "full.pt"))
+    assert res["widths"] == [8] * 5
+    # launches of 8 heads and one launch of 40 differ at most in the last bf16 bit of a few outputs
+    assert res["max_diff"] <= 2.0 ** -8 * res["max_ref"], res
+    assert res["refused"]

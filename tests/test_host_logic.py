@@ -231,3 +231,22 @@ def test_static_scratch_entry_point_rejects_oversize_without_touching_the_gpu():
     p = (ctypes.addressof(buf) + 15) & ~15
     assert lib.lx2v_attn_fwd_fp8_static(p, 1536, p, 1536, p, 1536, p, 1536, 32760, 32760, 12, 128, 0.1, None) == -2
     assert b"fixed array" in lib.lx2v_last_error()
+
+
+def test_ulysses_chunk_count_follows_the_payload_limit():
+    """A chunk's q|k|v payload per peer stays under the limit RCCL moves whole: more, narrower head
+    chunks at sizes where two would not fit; multi-GPU shapes keep their default."""
+    from lightx2v_amd import ulysses
+
+    lim = ulysses.MAX_PEER_BYTES
+    assert lim == 512 << 20
+    # 14B at 720p on a group of one rank: 40 heads x 75 600 tokens = 2.3 GB -> five chunks of eight heads
+    c = ulysses.chunks_for_payload(40, 2, 75600, 128)
+    widths = ulysses.split_heads(40, c)
+    assert c == 5 and widths == [8] * 5
+    assert all(75600 * 3 * w * 128 * 2 <= lim for w in widths)
+    # groups of 2 / 4 / 8 at the same size keep the default chunk count
+    for world in (2, 4, 8):
+        assert ulysses.chunks_for_payload(40 // world, ulysses.default_chunks(world), 75600 // world, 128) == ulysses.default_chunks(world)
+    # never more chunks than heads
+    assert ulysses.chunks_for_payload(2, 1, 10**7, 128) == 2
