@@ -27,12 +27,15 @@ from .hy_block import (  # noqa: F401,E402
 )
 from .rope_table import build_rope_table, shard_rope_table  # noqa: F401,E402
 from .wan_model import (  # noqa: F401,E402
+    MultiDistillModelStruct,
     MultiModelStruct,
+    Wan22StepDistillScheduler,
     WanModel,
     WanPostInfer,
     WanPreInfer,
     WanPreWeights,
     WanScheduler,
+    WanStepDistillScheduler,
     run_denoise_loop,
 )
 from .hy_model import (  # noqa: F401,E402

@@ -149,10 +149,15 @@ class WanPreInfer:
             # mask + VAE latents of the conditioning image ride along as extra input channels
             # (pre_infer.py:37-53; in_dim = 16 + 20 for Wan2.2-A14B i2v)
             y = inputs["image_encoder_output"]["vae_encoder_out"]
+        else:
+            y = None
+        if y is not None:
             if round_now:
                 hip.patchify(latents, round_latents=True)
             x = weights.patch_embedding.apply(torch.cat([latents, y.to(latents.dtype)], dim=0))
         else:
+            # (also model_cls "wan2.2" i2v: the runner clears `vae_encoder_out` after scheduler.prepare,
+            # default_runner.py:282-285 -- the image lives on the first latent frame instead)
             x = weights.patch_embedding.apply(latents, round_latents=round_now)
         grid = (f // PATCH_SIZE[0], h // PATCH_SIZE[1], w // PATCH_SIZE[2])
         # One embedding per DISTINCT timestep.  A per-token timestep vector (Wan2.2 ti2v: 0 on the
@@ -234,6 +239,10 @@ class WanScheduler:
         self.transformer_infer = None
         self.cos_sin = None
         self.seq_p_group = config.get("seq_p_group") if config.get("seq_parallel") else None
+        # model_cls "wan2.2" (the dense ti2v model) with an image: the image's VAE latents sit on the
+        # first latent frame of the sample itself (scheduler.py:50-51,127-129,391-392,433-434)
+        self.image_in_latents = config.get("model_cls") == "wan2.2" and config.get("task") in ("i2v", "s2v")
+        self.vae_encoder_out: Optional[torch.Tensor] = None
 
     def clear(self):
         """Drop cached features between clips (schedulers/wan/feature_caching/scheduler.py:8-9)."""
@@ -244,8 +253,11 @@ class WanScheduler:
 
     # scheduler.py:49-76
     def prepare(self, seed, latent_shape, image_encoder_output=None, latents: Optional[torch.Tensor] = None):
+        if self.image_in_latents:
+            self.vae_encoder_out = image_encoder_output["vae_encoder_out"].to(device=self.device, dtype=torch.float32)
         if latents is not None:
             self.latents = latents.to(device=self.device, dtype=torch.float32).contiguous().clone()
+            self._keep_image_frame()
         else:
             self.prepare_latents(seed, latent_shape)
         alphas = np.linspace(1, 1 / self.num_train_timesteps, self.num_train_timesteps)[::-1].copy()
@@ -259,6 +271,13 @@ class WanScheduler:
     def prepare_latents(self, seed, latent_shape, dtype=torch.float32):
         self.generator = torch.Generator(device=self.device).manual_seed(seed)
         self.latents = torch.randn(*latent_shape, dtype=dtype, device=self.device, generator=self.generator)
+        self._keep_image_frame()
+
+    def _keep_image_frame(self):
+        """`(1 - mask) * vae_encoder_out + mask * latents` with the reference's mask (ones, zeros on the
+        first latent frame; lightx2v/utils/utils.py:451-461): a copy of that one frame, the same values."""
+        if self.image_in_latents:
+            self.latents[:, :1].copy_(self.vae_encoder_out[:, :1])
 
     def prepare_cos_sin(self, grid_sizes):
         """fp32 [S_local, head_dim] cos || sin table (scheduler.py:77-114), sharded under Ulysses."""
@@ -285,6 +304,12 @@ class WanScheduler:
     def step_pre(self, step_index):
         self.step_index = step_index
         self.timestep_input = torch.stack([self.timesteps[self.step_index]])
+        if self.image_in_latents:
+            # one timestep per token of the (1, 2, 2) patch grid: 0 on the image frame's tokens (scheduler.py:391-392)
+            _, f, h, w = self.latents.shape
+            per_frame = ((h + 1) // 2) * ((w + 1) // 2)
+            t = self.timestep_input.to(torch.float32).cpu()
+            self.timestep_input = torch.cat([torch.zeros(per_frame), t.expand((f - 1) * per_frame)])
         if not self.keep_latents_dtype_in_scheduler:
             # latents <- bf16(latents): done by the patch gather of the first forward of this step
             self.round_pending = True
@@ -357,6 +382,60 @@ class WanScheduler:
         if self.lower_order_nums < self.solver_order:
             self.lower_order_nums += 1
         self.latents = hip.lincomb(terms)
+        self._keep_image_frame()
+
+
+class WanStepDistillScheduler(WanScheduler):
+    """The step-distilled schedule (lightx2v/models/schedulers/wan/step_distill/scheduler.py:9-50): the
+    shifted sigma table of 1000 training steps sampled at `denoising_step_list`, Euler-type update
+    x <- x - sigma_i f + sigma_{i+1} f.  Used without CFG (configs/distill/*.json)."""
+
+    def __init__(self, config):
+        config = dict(config, infer_steps=len(config["denoising_step_list"]))
+        super().__init__(config)
+        self.denoising_step_list = list(config["denoising_step_list"])
+        self.sigma_max, self.sigma_min = 1.0, 0.0
+
+    def prepare(self, seed, latent_shape, image_encoder_output=None, latents: Optional[torch.Tensor] = None):
+        if latents is not None:
+            self.latents = latents.to(device=self.device, dtype=torch.float32).contiguous().clone()
+        else:
+            self.prepare_latents(seed, latent_shape)
+        self.set_denoising_timesteps()
+        self.cos_sin = self.prepare_cos_sin((latent_shape[1] // PATCH_SIZE[0], latent_shape[2] // PATCH_SIZE[1], latent_shape[3] // PATCH_SIZE[2]))
+
+    def set_denoising_timesteps(self):
+        sigmas = torch.linspace(self.sigma_max, self.sigma_min, self.num_train_timesteps + 1)[:-1]
+        sigmas = self.sample_shift * sigmas / (1 + (self.sample_shift - 1) * sigmas)
+        timesteps = sigmas * self.num_train_timesteps
+        index = [self.num_train_timesteps - x for x in self.denoising_step_list]
+        self.timesteps = timesteps[index]   # fp32, host side (the pre-infer reads it there)
+        self.sigmas = sigmas[index]
+
+    def reset(self, seed, latent_shape, step_index=None):
+        self.prepare_latents(seed, latent_shape)
+
+    def add_noise(self, original_samples, noise, sigma):
+        return hip.lincomb([(1.0 - float(sigma), original_samples), (float(sigma), noise)])
+
+    def step_post(self):
+        i = self.step_index
+        terms = [(1.0, self.latents), (-self.sigmas[i].item(), self.noise_pred)]
+        if i < self.infer_steps - 1:
+            terms.append((self.sigmas[i + 1].item(), self.noise_pred))
+        self.latents = hip.lincomb(terms)
+
+
+class Wan22StepDistillScheduler(WanStepDistillScheduler):
+    """step_distill/scheduler.py:52-76: the same update; keeps the boundary step and its sigma."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.boundary_step_index = config["boundary_step_index"]
+
+    def set_denoising_timesteps(self):
+        super().set_denoising_timesteps()
+        self.sigma_bound = self.sigmas[self.boundary_step_index].item()
 
 
 # ------------------------------------------------------------------------------- model
@@ -476,6 +555,18 @@ class MultiModelStruct:
         high = float(self.scheduler.timesteps[self.scheduler.step_index]) >= self.boundary_timestep
         self.cur_model_index = 0 if high else 1
         self.scheduler.sample_guide_scale = self.config["sample_guide_scale"][self.cur_model_index]
+
+
+class MultiDistillModelStruct(MultiModelStruct):
+    """The two-expert switch of the Wan2.2 step-distilled model (lightx2v/models/runners/wan/wan_distill_runner.py:44-75):
+    the high-noise expert runs while step_index < boundary_step_index; the guide scale is left alone."""
+
+    def __init__(self, model_list, config, boundary_step_index=2):
+        super().__init__(model_list, config)
+        self.boundary_step_index = boundary_step_index
+
+    def get_current_model_index(self):
+        self.cur_model_index = 0 if self.scheduler.step_index < self.boundary_step_index else 1
 
 
 def run_denoise_loop(model, inputs, infer_steps: Optional[int] = None):

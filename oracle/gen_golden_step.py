@@ -36,7 +36,7 @@ def build_model(dim, ffn, layers, text_dim, seed, in_dim=16):
     return model
 
 
-def reference_objects(cfg, model, layers):
+def reference_objects(cfg, model, layers, scheduler_cls=None):
     import lightx2v.common.ops  # noqa: F401
     from lightx2v.models.networks.wan.infer.post_infer import WanPostInfer
     from lightx2v.models.networks.wan.infer.pre_infer import WanPreInfer
@@ -75,7 +75,7 @@ def reference_objects(cfg, model, layers):
     head.head.bias = model["head.head.bias"]
     head.head_modulation = TENSOR_REGISTER["Default"]("head.modulation")
     head.head_modulation.tensor = model["head.modulation"]
-    sch = WanScheduler(cfg)
+    sch = (scheduler_cls or WanScheduler)(cfg)
     pre = WanPreInfer(cfg)
     post = WanPostInfer(cfg)
     for o in (pre, post, infer):
@@ -322,6 +322,131 @@ def run_per_token_case(name, latent_shape, dim, heads, ffn, layers, text_len, te
     print(f"{name}: per-token forward, |restatement - reference| = {d:.3e}")
 
 
+def _ref_forward(pre_w, blocks, head, pre, infer, post, sch, inputs, cond):
+    sch.infer_condition = cond
+    out = pre.infer(pre_w, inputs)
+    x = out.x
+    for blk in blocks:
+        x = infer.infer_block(blk, x, out)
+    return post.infer(infer.infer_non_blocks(head, x, out.embed), out)[0]
+
+
+def run_ti2v_case(name, latent_shape, dim, heads, ffn, layers, text_len, text_dim, steps, shift, guide, seed, out_dir):
+    """model_cls "wan2.2" (the dense ti2v model) with task i2v: the reference's WanScheduler keeps the VAE
+    latents of the conditioning image on the first latent frame (prepare_latents / step_post) and hands
+    the model a per-token timestep vector (step_pre); the runner clears `vae_encoder_out` from the
+    inputs after `prepare` (default_runner.py:282-285), so the pre-infer concatenates nothing."""
+    cfg = {
+        "dim": dim, "num_heads": heads, "num_layers": layers, "ffn_dim": ffn, "in_dim": 16, "out_dim": 16, "freq_dim": 256, "text_len": text_len,
+        "task": "i2v", "model_cls": "wan2.2", "use_image_encoder": False, "run_device": "cpu", "cpu_offload": False, "seq_parallel": False,
+        "cfg_parallel": False, "self_attn_1_type": "torch_sdpa", "cross_attn_1_type": "torch_sdpa", "cross_attn_2_type": "torch_sdpa",
+        "modulate_type": "torch", "rope_type": "torch", "infer_steps": steps, "target_video_length": 4 * (latent_shape[1] - 1) + 1,
+        "sample_shift": shift, "sample_guide_scale": guide, "enable_cfg": True, "feature_caching": "NoCaching",
+    }
+    model = build_model(dim, ffn, layers, text_dim, seed)
+    objs = reference_objects(cfg, model, layers)
+    pre_w, blocks, head, pre, infer, post, sch = objs
+    g = torch.Generator().manual_seed(seed * 7919 + 61)
+    context = torch.randn(text_len, text_dim, generator=g)
+    context_null = torch.randn(text_len, text_dim, generator=g)
+    z = torch.randn(16, 1, *latent_shape[2:], generator=g)   # VAE latents of the one conditioning image
+    inputs = {"text_encoder_output": {"context": context.unsqueeze(0), "context_null": context_null.unsqueeze(0)},
+              "image_encoder_output": {"vae_encoder_out": z}}
+    sch.prepare(seed, latent_shape, image_encoder_output=inputs["image_encoder_output"])
+    inputs["image_encoder_output"]["vae_encoder_out"] = None
+    noise0 = torch.randn(*latent_shape, generator=torch.Generator().manual_seed(seed))   # what prepare_latents drew before the blend
+    latents0 = sch.latents.clone()
+    assert torch.equal(latents0[:, 1:], noise0[:, 1:]) and torch.equal(latents0[:, :1], z)
+    infer.cos_sin = sch.cos_sin
+    store = {"noise0": noise0.numpy(), "latents0": latents0.numpy(), "context": context.numpy(), "context_null": context_null.numpy(), "z": z.numpy()}
+    for i in range(steps):
+        sch.step_pre(step_index=i)
+        store[f"timestep_input_{i}"] = sch.timestep_input.numpy().copy()
+        cond = _ref_forward(*objs, inputs, True)
+        uncond = _ref_forward(*objs, inputs, False)
+        sch.noise_pred = uncond + sch.sample_guide_scale * (cond - uncond)
+        sch.step_post()
+        store[f"noise_pred_{i}"] = sch.noise_pred.numpy()
+        store[f"latents_{i + 1}"] = sch.latents.numpy()
+    my0, my_preds, my_traj = T.sample_loop_ti2v(model, noise0, z, context, context_null, heads, layers, steps, shift, guide)
+    assert torch.equal(my0, latents0)
+    worst = 0.0
+    for i in range(steps):
+        assert torch.equal(T.ti2v_timestep(T.ti2v_mask(noise0), T.UniPC(steps, shift).timestep_input(i)), torch.from_numpy(store[f"timestep_input_{i}"]))
+        worst = max(worst, (my_preds[i] - torch.from_numpy(store[f"noise_pred_{i}"])).abs().max().item(),
+                    (my_traj[i] - torch.from_numpy(store[f"latents_{i + 1}"])).abs().max().item())
+    assert worst < 2e-4, worst
+    meta = dict(latent_shape=latent_shape, dim=dim, heads=heads, ffn=ffn, layers=layers, text_len=text_len, text_dim=text_dim, steps=steps,
+                shift=shift, guide=guide, seed=seed)
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), meta=np.array(repr(meta)), **store)
+    print(f"{name}: {steps} steps, worst |restatement - reference| = {worst:.3e}")
+
+
+def run_distill_case(name, latent_shape, dim, heads, ffn, layers, text_len, text_dim, step_list, shift, seed, out_dir, two_experts=False, boundary_step_index=2):
+    """The step-distilled loops: the reference's WanStepDistillScheduler (Wan2.1 distill, t2v, one model) or
+    Wan22StepDistillScheduler (Wan2.2 two-expert distill, i2v with 20 conditioning channels), no CFG, one
+    forward per step; for two experts the switch is MultiDistillModelStruct's rule (restated: its module's
+    import chain needs absent packages)."""
+    from lightx2v.models.schedulers.wan.step_distill.scheduler import Wan22StepDistillScheduler, WanStepDistillScheduler
+
+    in_dim = 36 if two_experts else 16
+    cfg = {
+        "dim": dim, "num_heads": heads, "num_layers": layers, "ffn_dim": ffn, "in_dim": in_dim, "out_dim": 16, "freq_dim": 256, "text_len": text_len,
+        "task": "i2v" if two_experts else "t2v", "model_cls": "wan2.2_moe_distill" if two_experts else "wan2.1_distill", "use_image_encoder": False,
+        "run_device": "cpu", "cpu_offload": False, "seq_parallel": False, "cfg_parallel": False,
+        "self_attn_1_type": "torch_sdpa", "cross_attn_1_type": "torch_sdpa", "cross_attn_2_type": "torch_sdpa", "modulate_type": "torch", "rope_type": "torch",
+        "infer_steps": len(step_list), "denoising_step_list": list(step_list), "boundary_step_index": boundary_step_index,
+        "target_video_length": 4 * (latent_shape[1] - 1) + 1, "sample_shift": shift, "sample_guide_scale": 5.0, "enable_cfg": False, "feature_caching": "NoCaching",
+    }
+    n_models = 2 if two_experts else 1
+    models = [build_model(dim, ffn, layers, text_dim, seed + e, in_dim=in_dim) for e in range(n_models)]
+    experts = [reference_objects(cfg, m, layers, scheduler_cls=Wan22StepDistillScheduler if two_experts else WanStepDistillScheduler) for m in models]
+    sch = experts[0][6]
+    for e in experts:
+        for o in (e[3], e[5], e[4]):
+            o.set_scheduler(sch)
+    g = torch.Generator().manual_seed(seed * 7919 + 71)
+    context = torch.randn(text_len, text_dim, generator=g)
+    inputs = {"text_encoder_output": {"context": context.unsqueeze(0), "context_null": context.unsqueeze(0)}}
+    y = None
+    if two_experts:
+        y = torch.randn(20, *latent_shape[1:], generator=g)
+        inputs["image_encoder_output"] = {"vae_encoder_out": y}
+    sch.prepare(seed, latent_shape)
+    latents0 = sch.latents.clone()
+    for e in experts:
+        e[4].cos_sin = sch.cos_sin
+    store = {"latents0": latents0.numpy(), "context": context.numpy(), "timesteps": sch.timesteps.numpy(), "sigmas": sch.sigmas.numpy()}
+    if y is not None:
+        store["y"] = y.numpy()
+    picks = []
+    for i in range(len(step_list)):
+        sch.step_pre(step_index=i)
+        which = 0 if (not two_experts or sch.step_index < boundary_step_index) else 1
+        pre_w, blocks, head, pre, infer, post, _ = experts[which]
+        sch.noise_pred = _ref_forward(pre_w, blocks, head, pre, infer, post, sch, inputs, True)
+        sch.step_post()
+        store[f"noise_pred_{i}"] = sch.noise_pred.numpy()
+        store[f"latents_{i + 1}"] = sch.latents.numpy()
+        picks.append(which)
+    mine = T.StepDistill(step_list, shift)
+    assert torch.equal(mine.timesteps, sch.timesteps) and torch.equal(mine.sigmas, sch.sigmas)
+    my_preds, my_traj, my_picks = T.sample_loop_distill(models, boundary_step_index, latents0, context, heads, layers, step_list, shift, y=y)
+    assert my_picks == picks
+    worst = max(max((a - torch.from_numpy(store[f"noise_pred_{i}"])).abs().max().item() for i, a in enumerate(my_preds)),
+                max((a - torch.from_numpy(store[f"latents_{i + 1}"])).abs().max().item() for i, a in enumerate(my_traj)))
+    assert worst < 2e-4, worst
+    # the scheduler alone on the reference's own predictions: bit for bit
+    lat = latents0
+    for i in range(len(step_list)):
+        lat = mine.step(i, torch.from_numpy(store[f"noise_pred_{i}"]), lat)
+        assert torch.equal(lat, torch.from_numpy(store[f"latents_{i + 1}"])), i
+    meta = dict(latent_shape=latent_shape, dim=dim, heads=heads, ffn=ffn, layers=layers, text_len=text_len, text_dim=text_dim, step_list=list(step_list),
+                shift=shift, seed=seed, two_experts=two_experts, boundary_step_index=boundary_step_index, picks=picks)
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), meta=np.array(repr(meta)), **store)
+    print(f"{name}: {len(step_list)} distilled steps, experts {picks}, worst |restatement - reference| = {worst:.3e}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -334,6 +459,16 @@ def main():
         with torch.no_grad():
             run_per_token_case("step_per_token_d256", (16, 3, 8, 12), 256, 2, 512, 2, 16, 128, 13, a.out)
         return
+    extra = {
+        "step_ti2v_d256": lambda: run_ti2v_case("step_ti2v_d256", (16, 3, 8, 12), 256, 2, 512, 2, 16, 128, 4, 5.0, 5.0, 21, a.out),
+        "step_distill_d256": lambda: run_distill_case("step_distill_d256", (16, 3, 8, 12), 256, 2, 512, 2, 16, 128, [1000, 750, 500, 250], 5.0, 23, a.out),
+        "step_distill_moe_i2v_d256": lambda: run_distill_case("step_distill_moe_i2v_d256", (16, 3, 8, 12), 256, 2, 512, 1, 16, 128, [1000, 750, 500, 250], 5.0, 27, a.out,
+                                                              two_experts=True, boundary_step_index=2),
+    }
+    if a.only in extra:
+        with torch.no_grad():
+            extra[a.only]()
+        return
     if a.only == "step_clip_i2v_d256":
         with torch.no_grad():
             run_clip_i2v_case("step_clip_i2v_d256", (16, 3, 8, 12), 256, 2, 512, 2, 16, 128, 128, 3, 5.0, 5.0, 9, a.out)
@@ -344,6 +479,8 @@ def main():
         run_case("step_tiny_d256", (16, 3, 8, 12), 256, 2, 512, 2, 16, 128, 6, 5.0, 5.0, 3, a.out)
         run_case("step_small_d512", (16, 2, 12, 16), 512, 4, 1024, 2, 32, 256, 4, 3.0, 4.0, 5, a.out)
         run_two_expert_case("step_moe_i2v_d256", (16, 3, 8, 12), 256, 2, 512, 1, 16, 128, 6, 5.0, (3.5, 3.0), 0.6, 7, a.out)
+        for fn in extra.values():
+            fn()
 
 
 if __name__ == "__main__":

@@ -277,6 +277,96 @@ def sample_loop_two_experts(models, boundary: float, guides, latents0: torch.Ten
     return latents, traj, picks
 
 
+# --------------------------------------------------------------------------- Wan2.2 ti2v (dense, i2v / s2v)
+def ti2v_mask(latents: torch.Tensor) -> torch.Tensor:
+    """`masks_like(latents, zero=True)` without a generator (lightx2v/utils/utils.py:451-461): ones,
+    zeros on the first latent frame."""
+    m = torch.ones_like(latents)
+    m[:, :1] = 0
+    return m
+
+
+def ti2v_blend(latents: torch.Tensor, z: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """scheduler.py:127-129 and :433-434: the VAE latents of the conditioning image `z` ([C, 1, H, W]
+    or [C, F, H, W]) replace the masked frame of the latents."""
+    return (1.0 - mask) * z + mask * latents
+
+
+def ti2v_timestep(mask: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    """scheduler.py:391-392: one timestep per token of the (1, 2, 2) patch grid -- 0 on the tokens of
+    the conditioning frame, t elsewhere."""
+    return (mask[0][:, ::2, ::2] * t).flatten()
+
+
+def sample_loop_ti2v(model, noise0: torch.Tensor, z: torch.Tensor, context: torch.Tensor, context_null: torch.Tensor, num_heads: int,
+                     num_layers: int, infer_steps: int, sample_shift: float, guide: float):
+    """The denoise loop of model_cls "wan2.2" with task i2v (default_runner.py:275-285 +
+    scheduler.py:49-51,116-129,388-392,433-434): the image enters through the latents, not through
+    extra channels -- `prepare_latents` and every `step_post` put `z` back on the first frame, and
+    every forward sees a per-token timestep vector.  Returns (latents0, per-step predictions, per-step latents)."""
+    sch = UniPC(infer_steps, sample_shift)
+    mask = ti2v_mask(noise0)
+    latents = ti2v_blend(noise0, z, mask)
+    latents0, preds, traj = latents, [], []
+    for i in range(infer_steps):
+        t = ti2v_timestep(mask, sch.timestep_input(i))
+        cond = forward(model, latents, t, context, num_heads, num_layers)
+        uncond = forward(model, latents, t, context_null, num_heads, num_layers)
+        pred = cfg_combine(cond, uncond, guide)
+        latents = ti2v_blend(sch.step(i, pred, latents), z, mask)
+        preds.append(pred)
+        traj.append(latents)
+    return latents0, preds, traj
+
+
+# --------------------------------------------------------------------------- step-distilled schedule
+class StepDistill:
+    """`WanStepDistillScheduler` restated (lightx2v/models/schedulers/wan/step_distill/scheduler.py:9-50):
+    the shifted sigma table of 1000 training steps sampled at `denoising_step_list`, and an Euler-type
+    update x <- (x - sigma_i f) + sigma_{i+1} f (no second term on the last step)."""
+
+    def __init__(self, denoising_step_list, sample_shift: float, num_train_timesteps: int = 1000):
+        self.infer_steps = len(denoising_step_list)
+        sigmas = torch.linspace(1.0, 0.0, num_train_timesteps + 1)[:-1]                   # :27-28 (sigma_max 1, sigma_min 0)
+        sigmas = sample_shift * sigmas / (1 + (sample_shift - 1) * sigmas)               # :29
+        timesteps = sigmas * num_train_timesteps                                         # :30
+        index = [num_train_timesteps - x for x in denoising_step_list]                    # :32
+        self.timesteps = timesteps[index]
+        self.sigmas = sigmas[index]
+
+    def timestep_input(self, step_index: int) -> torch.Tensor:
+        return torch.stack([self.timesteps[step_index]])
+
+    def step(self, step_index: int, flow_pred: torch.Tensor, latents: torch.Tensor) -> torch.Tensor:
+        """step_post(): :43-50."""
+        flow_pred = flow_pred.to(torch.float32)
+        sigma = self.sigmas[step_index].item()
+        out = latents.to(torch.float32) - sigma * flow_pred
+        if step_index < self.infer_steps - 1:
+            out = out + flow_pred * self.sigmas[step_index + 1].item()
+        return out.to(latents.dtype)
+
+
+def sample_loop_distill(models, boundary_step_index: int, latents0: torch.Tensor, context: torch.Tensor, num_heads: int, num_layers: int,
+                        denoising_step_list, sample_shift: float, y: Optional[torch.Tensor] = None):
+    """The step-distilled loop, no CFG (`enable_cfg` false in configs/distill/*.json): one forward per
+    step.  `models` = [model] for Wan2.1 distill, or [high, low] for the Wan2.2 two-expert distill,
+    where `MultiDistillModelStruct` (lightx2v/models/runners/wan/wan_distill_runner.py:44-75) runs the
+    high-noise expert while step_index < boundary_step_index.  `Wan22StepDistillScheduler.step_post`
+    (step_distill/scheduler.py:66-76) is the same update as its base class.
+    Returns (per-step predictions, per-step latents, per-step expert index)."""
+    sch = StepDistill(denoising_step_list, sample_shift)
+    latents, preds, traj, picks = latents0, [], [], []
+    for i in range(sch.infer_steps):
+        which = 0 if (len(models) == 1 or i < boundary_step_index) else 1
+        pred = forward(models[which], latents, sch.timestep_input(i), context, num_heads, num_layers, y=y)
+        latents = sch.step(i, pred, latents)
+        preds.append(pred)
+        traj.append(latents)
+        picks.append(which)
+    return preds, traj, picks
+
+
 # --------------------------------------------------------------------------- TeaCache
 class TeaCache:
     """Skip logic of `WanTransformerInferTeaCaching`

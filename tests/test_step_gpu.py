@@ -319,3 +319,75 @@ def test_magcache_calibration_statistics(cuda):
     assert abs(infer.norm_ratio[0][2] - ratio.mean().item()) < 2e-2 and abs(infer.norm_std[0][2] - ratio.std().item()) < 2e-2
     want = (1 - torch.nn.functional.cosine_similarity(kept[2], kept[1], dim=-1)).mean().item()
     assert abs(infer.cos_dis[0][2] - want) < 2e-2
+
+
+def test_ti2v_loop_against_reference_trajectory(cuda):
+    """model_cls "wan2.2" with task i2v (the dense ti2v model): the image's VAE latents stay on the first
+    latent frame through prepare / every step_post, the model sees a per-token timestep vector (row
+    modulation kernels), nothing is concatenated in the pre-infer."""
+    from tests.test_step_oracle import plain_case
+
+    rec, meta, (model,) = plain_case("step_ti2v_d256")
+    m, sch = _model(meta, model, cuda, task="i2v", model_cls="wan2.2", use_image_encoder=False, keep_latents_dtype_in_scheduler=True)
+    z = torch.from_numpy(rec["z"])
+    inputs = {"text_encoder_output": {"context": torch.from_numpy(rec["context"]).to(cuda), "context_null": torch.from_numpy(rec["context_null"]).to(cuda)},
+              "image_encoder_output": {"vae_encoder_out": z.to(cuda)}}
+    sch.prepare(meta["seed"], meta["latent_shape"], image_encoder_output=inputs["image_encoder_output"], latents=torch.from_numpy(rec["noise0"]))
+    inputs["image_encoder_output"]["vae_encoder_out"] = None   # as the reference's runner does after prepare
+    assert torch.equal(sch.latents.cpu(), torch.from_numpy(rec["latents0"]))
+    for i in range(meta["steps"]):
+        sch.step_pre(i)
+        assert torch.equal(sch.timestep_input.cpu(), torch.from_numpy(rec[f"timestep_input_{i}"]))
+        m.infer(inputs)
+        assert cos(sch.noise_pred, torch.from_numpy(rec[f"noise_pred_{i}"])) >= 0.999, i
+        sch.step_post()
+        assert torch.equal(sch.latents[:, :1].cpu(), z)
+    final = torch.from_numpy(rec[f"latents_{meta['steps']}"])
+    err, c = rel_err(sch.latents, final), cos(sch.latents, final)
+    print(f"\nti2v loop: final-latent max-rel-err {err:.3e}, cosine {c:.6f}")
+    assert err <= 3e-2 and c >= 0.9995
+
+
+@pytest.mark.parametrize("name,in_dim,experts", [("step_distill_d256", 16, 1), ("step_distill_moe_i2v_d256", 36, 2)])
+def test_distill_loops_against_reference_trajectory(cuda, name, in_dim, experts):
+    """The 4-step distilled loops without CFG: Wan2.1 distill (one model, t2v) and the Wan2.2 two-expert
+    distill (i2v, 36 input channels, experts switched on the step index)."""
+    from tests.test_step_oracle import plain_case
+
+    rec, meta, models = plain_case(name, in_dim, experts)
+    cfg = {"dim": meta["dim"], "num_heads": meta["heads"], "num_layers": meta["layers"], "ffn_dim": meta["ffn"], "in_dim": in_dim, "out_dim": 16,
+           "freq_dim": 256, "task": "i2v" if experts == 2 else "t2v", "use_image_encoder": False, "infer_steps": 4, "denoising_step_list": meta["step_list"],
+           "boundary_step_index": meta["boundary_step_index"], "sample_shift": meta["shift"], "sample_guide_scale": 5.0, "enable_cfg": False,
+           "run_device": "cuda", "keep_latents_dtype_in_scheduler": True}
+    nets = [L.WanModel(cfg, weight_dict=dict(w)) for w in models]
+    if experts == 2:
+        model = L.MultiDistillModelStruct(nets, cfg, boundary_step_index=meta["boundary_step_index"])
+        sch = L.Wan22StepDistillScheduler(cfg)
+    else:
+        model, sch = nets[0], L.WanStepDistillScheduler(cfg)
+    model.to_cuda()
+    model.set_scheduler(sch)
+    sch.prepare(meta["seed"], meta["latent_shape"], latents=torch.from_numpy(rec["latents0"]))
+    inputs = {"text_encoder_output": {"context": torch.from_numpy(rec["context"]).to(cuda), "context_null": torch.from_numpy(rec["context"]).to(cuda)}}
+    if "y" in rec:
+        inputs["image_encoder_output"] = {"vae_encoder_out": torch.from_numpy(rec["y"]).to(cuda)}
+    picks = []
+    for i in range(4):
+        sch.step_pre(i)
+        model.infer(inputs)
+        picks.append(getattr(model, "cur_model_index", 0))
+        assert cos(sch.noise_pred, torch.from_numpy(rec[f"noise_pred_{i}"])) >= 0.999, i
+        sch.step_post()
+    assert picks == meta["picks"]
+    final = torch.from_numpy(rec["latents_4"])
+    err, c = rel_err(sch.latents, final), cos(sch.latents, final)
+    print(f"\n{name}: final-latent max-rel-err {err:.3e}, cosine {c:.6f}")
+    assert err <= 3e-2 and c >= 0.9995
+    # the scheduler alone on the reference's predictions
+    sch.prepare(meta["seed"], meta["latent_shape"], latents=torch.from_numpy(rec["latents0"]))
+    for i in range(4):
+        sch.step_pre(i)
+        sch.noise_pred = torch.from_numpy(rec[f"noise_pred_{i}"]).to(cuda)
+        sch.step_post()
+        ref = torch.from_numpy(rec[f"latents_{i + 1}"])
+        assert (sch.latents.cpu() - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item()), i

@@ -238,3 +238,107 @@ def test_magcache_decision_is_pure_host_logic():
         for i in range(meta["steps"]):
             for cond in (True, False):
                 assert mine.should_skip(i, cond) == (not ref.should_calc(i, cond)), (thresh, K, i, cond)
+
+
+# ---- Wan2.2 ti2v (image on the first latent frame) and the step-distilled schedules ----
+def plain_case(name, in_dim=16, experts=1):
+    rec = load_golden(name)
+    meta = ast.literal_eval(str(rec["meta"]))
+    models = []
+    for e in range(experts):
+        m = {}
+        for i in range(meta["layers"]):
+            m.update(R.make_block_weights(meta["dim"], meta["ffn"], seed=meta["seed"] + e, block_index=i))
+        m.update(R.make_head_weights(meta["dim"], 64, seed=meta["seed"] + e))
+        m.update(T.make_pre_weights(meta["dim"], in_dim, 256, meta["text_dim"], seed=meta["seed"] + e))
+        models.append(m)
+    return rec, meta, models
+
+
+def test_ti2v_loop_matches_reference_trajectory():
+    """model_cls "wan2.2", task i2v: the reference's own scheduler keeps the image's VAE latents on the
+    first latent frame and hands the model a per-token timestep vector; the restatement reproduces the
+    vectors bit for bit and the trajectory to rounding."""
+    rec, meta, (model,) = plain_case("step_ti2v_d256")
+    noise0, z = torch.from_numpy(rec["noise0"]), torch.from_numpy(rec["z"])
+    lat0, preds, traj = T.sample_loop_ti2v(model, noise0, z, torch.from_numpy(rec["context"]), torch.from_numpy(rec["context_null"]), meta["heads"],
+                                           meta["layers"], meta["steps"], meta["shift"], meta["guide"])
+    assert torch.equal(lat0, torch.from_numpy(rec["latents0"]))
+    mask = T.ti2v_mask(noise0)
+    sch = T.UniPC(meta["steps"], meta["shift"])
+    for i in range(meta["steps"]):
+        assert torch.equal(T.ti2v_timestep(mask, sch.timestep_input(i)), torch.from_numpy(rec[f"timestep_input_{i}"]))
+        assert (preds[i] - torch.from_numpy(rec[f"noise_pred_{i}"])).abs().max().item() <= 5e-4
+        assert (traj[i] - torch.from_numpy(rec[f"latents_{i + 1}"])).abs().max().item() <= 5e-4
+        assert torch.equal(traj[i][:, :1], z)   # the image frame never moves
+
+
+def test_product_ti2v_scheduler_host_logic():
+    """The product scheduler's image bookkeeping on host tensors: blended initial latents and the
+    per-token timestep vectors equal the reference's."""
+    import lightx2v_amd as L
+
+    rec, meta, _ = plain_case("step_ti2v_d256")
+    cfg = {"infer_steps": meta["steps"], "sample_shift": meta["shift"], "sample_guide_scale": meta["guide"], "dim": meta["dim"], "num_heads": meta["heads"],
+           "run_device": "cpu", "model_cls": "wan2.2", "task": "i2v", "keep_latents_dtype_in_scheduler": True}
+    sch = L.WanScheduler(cfg)
+    sch.prepare(meta["seed"], meta["latent_shape"], image_encoder_output={"vae_encoder_out": torch.from_numpy(rec["z"])}, latents=torch.from_numpy(rec["noise0"]))
+    assert torch.equal(sch.latents, torch.from_numpy(rec["latents0"]))
+    for i in range(meta["steps"]):
+        sch.step_pre(i)
+        assert torch.equal(sch.timestep_input, torch.from_numpy(rec[f"timestep_input_{i}"])), i
+    # a scheduler without an image keeps the scalar timestep
+    plain = L.WanScheduler(dict(cfg, model_cls="wan2.1", task="t2v"))
+    plain.prepare(0, meta["latent_shape"], latents=torch.from_numpy(rec["noise0"]))
+    plain.step_pre(0)
+    assert plain.timestep_input.numel() == 1
+
+
+@pytest.mark.parametrize("name,in_dim,experts", [("step_distill_d256", 16, 1), ("step_distill_moe_i2v_d256", 36, 2)])
+def test_distill_loops_match_reference_trajectory(name, in_dim, experts):
+    rec, meta, models = plain_case(name, in_dim, experts)
+    y = torch.from_numpy(rec["y"]) if "y" in rec else None
+    preds, traj, picks = T.sample_loop_distill(models, meta["boundary_step_index"], torch.from_numpy(rec["latents0"]), torch.from_numpy(rec["context"]),
+                                               meta["heads"], meta["layers"], meta["step_list"], meta["shift"], y=y)
+    assert picks == meta["picks"]
+    for i in range(len(meta["step_list"])):
+        assert (preds[i] - torch.from_numpy(rec[f"noise_pred_{i}"])).abs().max().item() <= 5e-4
+        assert (traj[i] - torch.from_numpy(rec[f"latents_{i + 1}"])).abs().max().item() <= 5e-4
+    # the scheduler alone on the reference's predictions: bit for bit
+    sch = T.StepDistill(meta["step_list"], meta["shift"])
+    assert torch.equal(sch.timesteps, torch.from_numpy(rec["timesteps"])) and torch.equal(sch.sigmas, torch.from_numpy(rec["sigmas"]))
+    lat = torch.from_numpy(rec["latents0"])
+    for i in range(len(meta["step_list"])):
+        lat = sch.step(i, torch.from_numpy(rec[f"noise_pred_{i}"]), lat)
+        assert torch.equal(lat, torch.from_numpy(rec[f"latents_{i + 1}"])), i
+
+
+def test_product_distill_scheduler_tables_and_switch():
+    """The product's step-distilled scheduler holds the reference's timesteps and sigmas bit for bit;
+    the two-expert struct switches on the step index."""
+    import lightx2v_amd as L
+
+    rec, meta, _ = plain_case("step_distill_moe_i2v_d256", 36, 2)
+    cfg = {"denoising_step_list": meta["step_list"], "boundary_step_index": meta["boundary_step_index"], "infer_steps": 50, "sample_shift": meta["shift"],
+           "sample_guide_scale": 5.0, "dim": meta["dim"], "num_heads": meta["heads"], "run_device": "cpu"}
+    sch = L.Wan22StepDistillScheduler(cfg)
+    sch.prepare(meta["seed"], meta["latent_shape"], latents=torch.from_numpy(rec["latents0"]))
+    assert sch.infer_steps == 4
+    assert torch.equal(sch.timesteps, torch.from_numpy(rec["timesteps"])) and torch.equal(sch.sigmas, torch.from_numpy(rec["sigmas"]))
+    assert sch.sigma_bound == float(rec["sigmas"][meta["boundary_step_index"]])
+
+    class FakeModel:
+        def set_scheduler(self, s):
+            pass
+
+        def infer(self, inputs):
+            pass
+
+    mm = L.MultiDistillModelStruct([FakeModel(), FakeModel()], cfg, boundary_step_index=meta["boundary_step_index"])
+    mm.set_scheduler(sch)
+    picks = []
+    for i in range(4):
+        sch.step_pre(i)
+        mm.infer(None)
+        picks.append(mm.cur_model_index)
+    assert picks == meta["picks"] and sch.sample_guide_scale == 5.0
