@@ -106,6 +106,11 @@ class WanPreWeights(WeightModule):
         self.add_module("time_embedding_0", mm("time_embedding.0.weight", "time_embedding.0.bias"))
         self.add_module("time_embedding_2", mm("time_embedding.2.weight", "time_embedding.2.bias"))
         self.add_module("time_projection_1", mm("time_projection.1.weight", "time_projection.1.bias"))
+        if config.get("model_cls") == "wan2.1_distill" and config.get("enable_dynamic_cfg", False):
+            # the distilled guidance embedding (pre_weights.py:60-69)
+            bf = MM_WEIGHT_REGISTER["hip-bf16"]
+            self.add_module("cfg_cond_proj_1", bf("guidance_embedding.linear_1.weight", "guidance_embedding.linear_1.bias"))
+            self.add_module("cfg_cond_proj_2", bf("guidance_embedding.linear_2.weight", "guidance_embedding.linear_2.bias"))
         if config["task"] == "i2v" and config.get("use_image_encoder", True):
             # CLIP image tokens -> LN, Linear, GELU, Linear, LN (pre_weights.py:43-59); never quantised there
             ln, bf = LN_WEIGHT_REGISTER["hip"], MM_WEIGHT_REGISTER["hip-bf16"]
@@ -113,6 +118,20 @@ class WanPreWeights(WeightModule):
             self.add_module("proj_1", bf("img_emb.proj.1.weight", "img_emb.proj.1.bias"))
             self.add_module("proj_3", bf("img_emb.proj.3.weight", "img_emb.proj.3.bias"))
             self.add_module("proj_4", ln("img_emb.proj.4.weight", "img_emb.proj.4.bias"))
+
+
+def guidance_scale_embedding(cfg_scale: float, embedding_dim: int = 256, cfg_range=(1.0, 6.0), target_range: float = 1000.0) -> torch.Tensor:
+    """The constant [1, 256] input of the distilled guidance embedding (lightx2v/models/networks/wan/infer/utils.py:218-242):
+    the guide scale rounded, clamped to `cfg_range`, mapped to [0, target_range], embedded as sin || cos.
+    One vector per model configuration, formed on the host like the RoPE table."""
+    lo, hi = cfg_range
+    w = torch.clamp(torch.round(torch.tensor([float(cfg_scale)], dtype=torch.float32)), min=lo, max=hi)
+    w = (w - lo) / (hi - lo) * target_range
+    half = embedding_dim // 2
+    step = torch.log(torch.tensor(10000.0)) / (half - 1)
+    freqs = torch.exp(torch.arange(half, dtype=torch.float32) * -step)
+    ang = w[:, None] * freqs[None, :]
+    return torch.cat([torch.sin(ang), torch.cos(ang)], dim=1)
 
 
 class GridOutput:
@@ -129,8 +148,9 @@ class WanPreInfer:
         self.task = config.get("task", "t2v")
         self.freq_dim = config["freq_dim"]
         self.dim = config["dim"]
-        if config.get("enable_dynamic_cfg", False):
-            raise NotImplementedError("enable_dynamic_cfg (distilled guidance embedding) is not built")
+        self.enable_dynamic_cfg = config.get("enable_dynamic_cfg", False)
+        self.cfg_scale = config.get("cfg_scale", 4.0)
+        self._cfg_embed_in: Optional[torch.Tensor] = None
         self.scheduler = None
 
     def set_scheduler(self, scheduler):
@@ -166,6 +186,12 @@ class WanPreInfer:
         t_all = sch.timestep_input.flatten().to("cpu")
         t_unique, inverse = (t_all, None) if t_all.numel() == 1 else torch.unique(t_all, return_inverse=True)
         embed = torch.cat([hip.timestep_embedding(float(t), self.freq_dim, latents.device) for t in t_unique], dim=0)
+        if self.enable_dynamic_cfg:
+            # pre_infer.py:67-73: the guide scale, embedded and projected, is added to the sinusoidal embedding
+            if self._cfg_embed_in is None or self._cfg_embed_in.device != latents.device:
+                self._cfg_embed_in = guidance_scale_embedding(self.cfg_scale).to(torch.bfloat16).to(latents.device)
+            ce = weights.cfg_cond_proj_2.apply(hip.silu(weights.cfg_cond_proj_1.apply(self._cfg_embed_in)))
+            embed = hip.add_rowvec(embed, ce.reshape(-1).contiguous())
         embed = weights.time_embedding_0.apply(embed)
         embed = hip.silu(embed)
         embed = weights.time_embedding_2.apply(embed)

@@ -51,6 +51,9 @@ def reference_objects(cfg, model, layers, scheduler_cls=None):
         mm = getattr(pre_w, attr)
         mm.weight = model[key + ".weight"].t()
         mm.bias = model[key + ".bias"]
+    if hasattr(pre_w, "cfg_cond_proj_1"):  # wan2.1_distill with enable_dynamic_cfg
+        for attr, key in (("cfg_cond_proj_1", "guidance_embedding.linear_1"), ("cfg_cond_proj_2", "guidance_embedding.linear_2")):
+            getattr(pre_w, attr).weight, getattr(pre_w, attr).bias = model[key + ".weight"].t(), model[key + ".bias"]
     if hasattr(pre_w, "proj_0"):  # i2v with a CLIP image encoder: img_emb.proj.{0,1,3,4}
         for attr, key in (("proj_0", "img_emb.proj.0"), ("proj_4", "img_emb.proj.4")):
             getattr(pre_w, attr).weight, getattr(pre_w, attr).bias = model[key + ".weight"], model[key + ".bias"]
@@ -382,7 +385,8 @@ def run_ti2v_case(name, latent_shape, dim, heads, ffn, layers, text_len, text_di
     print(f"{name}: {steps} steps, worst |restatement - reference| = {worst:.3e}")
 
 
-def run_distill_case(name, latent_shape, dim, heads, ffn, layers, text_len, text_dim, step_list, shift, seed, out_dir, two_experts=False, boundary_step_index=2):
+def run_distill_case(name, latent_shape, dim, heads, ffn, layers, text_len, text_dim, step_list, shift, seed, out_dir, two_experts=False, boundary_step_index=2,
+                     cfg_scale=None):
     """The step-distilled loops: the reference's WanStepDistillScheduler (Wan2.1 distill, t2v, one model) or
     Wan22StepDistillScheduler (Wan2.2 two-expert distill, i2v with 20 conditioning channels), no CFG, one
     forward per step; for two experts the switch is MultiDistillModelStruct's rule (restated: its module's
@@ -400,6 +404,10 @@ def run_distill_case(name, latent_shape, dim, heads, ffn, layers, text_len, text
     }
     n_models = 2 if two_experts else 1
     models = [build_model(dim, ffn, layers, text_dim, seed + e, in_dim=in_dim) for e in range(n_models)]
+    if cfg_scale is not None:  # the distilled guidance embedding (configs/distill/wan_t2v_distill_4step_cfg_dynamic.json)
+        cfg.update({"enable_dynamic_cfg": True, "cfg_scale": cfg_scale})
+        for e, m in enumerate(models):
+            m.update(T.make_guidance_weights(dim, 256, seed=seed + e))
     experts = [reference_objects(cfg, m, layers, scheduler_cls=Wan22StepDistillScheduler if two_experts else WanStepDistillScheduler) for m in models]
     sch = experts[0][6]
     for e in experts:
@@ -431,7 +439,7 @@ def run_distill_case(name, latent_shape, dim, heads, ffn, layers, text_len, text
         picks.append(which)
     mine = T.StepDistill(step_list, shift)
     assert torch.equal(mine.timesteps, sch.timesteps) and torch.equal(mine.sigmas, sch.sigmas)
-    my_preds, my_traj, my_picks = T.sample_loop_distill(models, boundary_step_index, latents0, context, heads, layers, step_list, shift, y=y)
+    my_preds, my_traj, my_picks = T.sample_loop_distill(models, boundary_step_index, latents0, context, heads, layers, step_list, shift, y=y, cfg_scale=cfg_scale)
     assert my_picks == picks
     worst = max(max((a - torch.from_numpy(store[f"noise_pred_{i}"])).abs().max().item() for i, a in enumerate(my_preds)),
                 max((a - torch.from_numpy(store[f"latents_{i + 1}"])).abs().max().item() for i, a in enumerate(my_traj)))
@@ -442,7 +450,7 @@ def run_distill_case(name, latent_shape, dim, heads, ffn, layers, text_len, text
         lat = mine.step(i, torch.from_numpy(store[f"noise_pred_{i}"]), lat)
         assert torch.equal(lat, torch.from_numpy(store[f"latents_{i + 1}"])), i
     meta = dict(latent_shape=latent_shape, dim=dim, heads=heads, ffn=ffn, layers=layers, text_len=text_len, text_dim=text_dim, step_list=list(step_list),
-                shift=shift, seed=seed, two_experts=two_experts, boundary_step_index=boundary_step_index, picks=picks)
+                shift=shift, seed=seed, two_experts=two_experts, boundary_step_index=boundary_step_index, picks=picks, cfg_scale=cfg_scale)
     np.savez_compressed(os.path.join(out_dir, name + ".npz"), meta=np.array(repr(meta)), **store)
     print(f"{name}: {len(step_list)} distilled steps, experts {picks}, worst |restatement - reference| = {worst:.3e}")
 
@@ -462,6 +470,8 @@ def main():
     extra = {
         "step_ti2v_d256": lambda: run_ti2v_case("step_ti2v_d256", (16, 3, 8, 12), 256, 2, 512, 2, 16, 128, 4, 5.0, 5.0, 21, a.out),
         "step_distill_d256": lambda: run_distill_case("step_distill_d256", (16, 3, 8, 12), 256, 2, 512, 2, 16, 128, [1000, 750, 500, 250], 5.0, 23, a.out),
+        "step_distill_dyncfg_d256": lambda: run_distill_case("step_distill_dyncfg_d256", (16, 3, 8, 12), 256, 2, 512, 2, 16, 128, [1000, 750, 500, 250], 5.0, 31, a.out,
+                                                             cfg_scale=3.4),
         "step_distill_moe_i2v_d256": lambda: run_distill_case("step_distill_moe_i2v_d256", (16, 3, 8, 12), 256, 2, 512, 1, 16, 128, [1000, 750, 500, 250], 5.0, 27, a.out,
                                                               two_experts=True, boundary_step_index=2),
     }

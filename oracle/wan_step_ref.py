@@ -72,6 +72,30 @@ def img_emb(pw: Dict[str, torch.Tensor], clip_fea: torch.Tensor) -> torch.Tensor
 
 
 # --------------------------------------------------------------------------- pre / post infer
+def make_guidance_weights(dim: int, freq_dim: int = 256, seed: int = 0, dtype=torch.float32):
+    """Synthetic `guidance_embedding.linear_{1,2}` (pre_weights.py:60-69; model_cls "wan2.1_distill" with
+    `enable_dynamic_cfg`): 256 -> dim -> freq_dim, so that the result adds to the sinusoidal timestep embedding."""
+    g = torch.Generator().manual_seed(seed * 104729 + 977)
+    w = {}
+    for name, (o, i) in {"guidance_embedding.linear_1": (dim, 256), "guidance_embedding.linear_2": (freq_dim, dim)}.items():
+        w[name + ".weight"] = (torch.randn(o, i, generator=g) * 0.05).to(dtype)
+        w[name + ".bias"] = (torch.randn(o, generator=g) * 0.02).to(dtype)
+    return w
+
+
+def guidance_scale_embedding(w: torch.Tensor, embedding_dim: int = 256, cfg_range=(1.0, 6.0), target_range: float = 1000.0) -> torch.Tensor:
+    """lightx2v/models/networks/wan/infer/utils.py:218-242: the guide scale rounded, clamped to `cfg_range`,
+    mapped to [0, target_range] and embedded as sin || cos over 10000^(-i/(half-1))."""
+    lo, hi = cfg_range
+    w = torch.clamp(torch.round(w), min=lo, max=hi)
+    w = (w - lo) / (hi - lo) * target_range
+    half = embedding_dim // 2
+    step = torch.log(torch.tensor(10000.0)) / (half - 1)
+    freqs = torch.exp(torch.arange(half, dtype=torch.float32) * -step)
+    ang = w.to(torch.float32)[:, None] * freqs[None, :]
+    return torch.cat([torch.sin(ang), torch.cos(ang)], dim=1)
+
+
 def sinusoidal_embedding_1d(dim: int, position: torch.Tensor) -> torch.Tensor:
     """utils.py:205-215: [cos(p * 10000^(-i/half)) || sin(...)], i < half."""
     half = dim // 2
@@ -89,7 +113,7 @@ def patchify(latents: torch.Tensor) -> torch.Tensor:
 
 
 def pre_infer(pw: Dict[str, torch.Tensor], latents: torch.Tensor, t: torch.Tensor, context: torch.Tensor, freq_dim: int = 256,
-              y: Optional[torch.Tensor] = None, clip_fea: Optional[torch.Tensor] = None):
+              y: Optional[torch.Tensor] = None, clip_fea: Optional[torch.Tensor] = None, cfg_scale: Optional[float] = None):
     """pre_infer.py:27-126 for task t2v, and for i2v without the CLIP branch (`use_image_encoder`
     false, the Wan2.2 two-expert configuration): `y` = mask + VAE latents [C_y, F, H, W] is
     concatenated to the latents along channels before the patch embedding (:37-53).
@@ -100,6 +124,11 @@ def pre_infer(pw: Dict[str, torch.Tensor], latents: torch.Tensor, t: torch.Tenso
         latents = torch.cat([latents, y], dim=0)
     x = R.linear(patchify(latents), pw["patch_embedding.weight"].reshape(dim, -1), pw["patch_embedding.bias"])
     embed = sinusoidal_embedding_1d(freq_dim, t.flatten())
+    if cfg_scale is not None:  # `enable_dynamic_cfg` (pre_infer.py:67-73): the guide scale enters through the timestep embedding
+        ce = guidance_scale_embedding(torch.tensor([cfg_scale], dtype=torch.float32))
+        ce = R.linear(ce, pw["guidance_embedding.linear_1.weight"], pw["guidance_embedding.linear_1.bias"])
+        ce = R.linear(F.silu(ce), pw["guidance_embedding.linear_2.weight"], pw["guidance_embedding.linear_2.bias"])
+        embed = embed + ce
     embed = R.linear(embed, pw["time_embedding.0.weight"], pw["time_embedding.0.bias"])
     embed = F.silu(embed)
     embed = R.linear(embed, pw["time_embedding.2.weight"], pw["time_embedding.2.bias"])
@@ -121,9 +150,9 @@ def unpatchify(x: torch.Tensor, grid: Tuple[int, int, int], out_dim: int = 16) -
 
 
 def forward(model: Dict[str, torch.Tensor], latents: torch.Tensor, t: torch.Tensor, context: torch.Tensor, num_heads: int, num_layers: int,
-            cos_sin=None, y: Optional[torch.Tensor] = None, clip_fea: Optional[torch.Tensor] = None) -> torch.Tensor:
+            cos_sin=None, y: Optional[torch.Tensor] = None, clip_fea: Optional[torch.Tensor] = None, cfg_scale: Optional[float] = None) -> torch.Tensor:
     """`_infer_cond_uncond` (model.py:447-466): one DiT forward -> noise prediction [16, F, H, W] fp32."""
-    x, embed, embed0, ctx, grid = pre_infer(model, latents, t, context, y=y, clip_fea=clip_fea)
+    x, embed, embed0, ctx, grid = pre_infer(model, latents, t, context, y=y, clip_fea=clip_fea, cfg_scale=cfg_scale)
     if cos_sin is None:
         cos_sin = R.build_cos_sin(grid, model["patch_embedding.bias"].shape[0] // num_heads)
     for i in range(num_layers):
@@ -348,7 +377,7 @@ class StepDistill:
 
 
 def sample_loop_distill(models, boundary_step_index: int, latents0: torch.Tensor, context: torch.Tensor, num_heads: int, num_layers: int,
-                        denoising_step_list, sample_shift: float, y: Optional[torch.Tensor] = None):
+                        denoising_step_list, sample_shift: float, y: Optional[torch.Tensor] = None, cfg_scale: Optional[float] = None):
     """The step-distilled loop, no CFG (`enable_cfg` false in configs/distill/*.json): one forward per
     step.  `models` = [model] for Wan2.1 distill, or [high, low] for the Wan2.2 two-expert distill,
     where `MultiDistillModelStruct` (lightx2v/models/runners/wan/wan_distill_runner.py:44-75) runs the
@@ -359,7 +388,7 @@ def sample_loop_distill(models, boundary_step_index: int, latents0: torch.Tensor
     latents, preds, traj, picks = latents0, [], [], []
     for i in range(sch.infer_steps):
         which = 0 if (len(models) == 1 or i < boundary_step_index) else 1
-        pred = forward(models[which], latents, sch.timestep_input(i), context, num_heads, num_layers, y=y)
+        pred = forward(models[which], latents, sch.timestep_input(i), context, num_heads, num_layers, y=y, cfg_scale=cfg_scale)
         latents = sch.step(i, pred, latents)
         preds.append(pred)
         traj.append(latents)

@@ -348,7 +348,7 @@ def test_ti2v_loop_against_reference_trajectory(cuda):
     assert err <= 3e-2 and c >= 0.9995
 
 
-@pytest.mark.parametrize("name,in_dim,experts", [("step_distill_d256", 16, 1), ("step_distill_moe_i2v_d256", 36, 2)])
+@pytest.mark.parametrize("name,in_dim,experts", [("step_distill_d256", 16, 1), ("step_distill_moe_i2v_d256", 36, 2), ("step_distill_dyncfg_d256", 16, 1)])
 def test_distill_loops_against_reference_trajectory(cuda, name, in_dim, experts):
     """The 4-step distilled loops without CFG: Wan2.1 distill (one model, t2v) and the Wan2.2 two-expert
     distill (i2v, 36 input channels, experts switched on the step index)."""
@@ -359,6 +359,8 @@ def test_distill_loops_against_reference_trajectory(cuda, name, in_dim, experts)
            "freq_dim": 256, "task": "i2v" if experts == 2 else "t2v", "use_image_encoder": False, "infer_steps": 4, "denoising_step_list": meta["step_list"],
            "boundary_step_index": meta["boundary_step_index"], "sample_shift": meta["shift"], "sample_guide_scale": 5.0, "enable_cfg": False,
            "run_device": "cuda", "keep_latents_dtype_in_scheduler": True}
+    if meta.get("cfg_scale") is not None:   # the distilled guidance embedding
+        cfg.update({"model_cls": "wan2.1_distill", "enable_dynamic_cfg": True, "cfg_scale": meta["cfg_scale"]})
     nets = [L.WanModel(cfg, weight_dict=dict(w)) for w in models]
     if experts == 2:
         model = L.MultiDistillModelStruct(nets, cfg, boundary_step_index=meta["boundary_step_index"])
@@ -379,6 +381,26 @@ def test_distill_loops_against_reference_trajectory(cuda, name, in_dim, experts)
         assert cos(sch.noise_pred, torch.from_numpy(rec[f"noise_pred_{i}"])) >= 0.999, i
         sch.step_post()
     assert picks == meta["picks"]
+    if meta.get("cfg_scale") is not None:
+        # the guidance embedding is live: the same model without it is measurably further from the reference's first prediction
+        plain = L.WanModel(dict(cfg, enable_dynamic_cfg=False), weight_dict=dict(models[0]))
+        plain.to_cuda()
+        sch0 = L.WanStepDistillScheduler(cfg)
+        for mdl, s_ in ((plain, sch0), (model, sch)):
+            mdl.set_scheduler(s_)
+            s_.prepare(meta["seed"], meta["latent_shape"], latents=torch.from_numpy(rec["latents0"]))
+            s_.step_pre(0)
+            mdl.infer(inputs)
+        gold0 = torch.from_numpy(rec["noise_pred_0"])
+        c_with, c_without = cos(sch.noise_pred, gold0), cos(sch0.noise_pred, gold0)
+        print(f"\ndynamic cfg: cosine of the first prediction with / without the guidance embedding {c_with:.6f} / {c_without:.6f}")
+        assert c_with >= 0.99995 and c_without <= 0.9999
+        # (restore the trajectory state for the checks below)
+        sch.prepare(meta["seed"], meta["latent_shape"], latents=torch.from_numpy(rec["latents0"]))
+        for i in range(4):
+            sch.step_pre(i)
+            model.infer(inputs)
+            sch.step_post()
     final = torch.from_numpy(rec["latents_4"])
     err, c = rel_err(sch.latents, final), cos(sch.latents, final)
     print(f"\n{name}: final-latent max-rel-err {err:.3e}, cosine {c:.6f}")

@@ -251,8 +251,17 @@ def plain_case(name, in_dim=16, experts=1):
             m.update(R.make_block_weights(meta["dim"], meta["ffn"], seed=meta["seed"] + e, block_index=i))
         m.update(R.make_head_weights(meta["dim"], 64, seed=meta["seed"] + e))
         m.update(T.make_pre_weights(meta["dim"], in_dim, 256, meta["text_dim"], seed=meta["seed"] + e))
+        if meta.get("cfg_scale") is not None:
+            m.update(T.make_guidance_weights(meta["dim"], 256, seed=meta["seed"] + e))
         models.append(m)
     return rec, meta, models
+
+
+def test_guidance_scale_embedding_equals_restatement():
+    from lightx2v_amd.wan_model import guidance_scale_embedding
+
+    for g in (0.0, 1.0, 3.4, 4.0, 5.5, 9.0):
+        assert torch.equal(guidance_scale_embedding(g), T.guidance_scale_embedding(torch.tensor([g])))
 
 
 def test_ti2v_loop_matches_reference_trajectory():
@@ -294,12 +303,12 @@ def test_product_ti2v_scheduler_host_logic():
     assert plain.timestep_input.numel() == 1
 
 
-@pytest.mark.parametrize("name,in_dim,experts", [("step_distill_d256", 16, 1), ("step_distill_moe_i2v_d256", 36, 2)])
+@pytest.mark.parametrize("name,in_dim,experts", [("step_distill_d256", 16, 1), ("step_distill_moe_i2v_d256", 36, 2), ("step_distill_dyncfg_d256", 16, 1)])
 def test_distill_loops_match_reference_trajectory(name, in_dim, experts):
     rec, meta, models = plain_case(name, in_dim, experts)
     y = torch.from_numpy(rec["y"]) if "y" in rec else None
     preds, traj, picks = T.sample_loop_distill(models, meta["boundary_step_index"], torch.from_numpy(rec["latents0"]), torch.from_numpy(rec["context"]),
-                                               meta["heads"], meta["layers"], meta["step_list"], meta["shift"], y=y)
+                                               meta["heads"], meta["layers"], meta["step_list"], meta["shift"], y=y, cfg_scale=meta.get("cfg_scale"))
     assert picks == meta["picks"]
     for i in range(len(meta["step_list"])):
         assert (preds[i] - torch.from_numpy(rec[f"noise_pred_{i}"])).abs().max().item() <= 5e-4
