@@ -493,12 +493,42 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
 // Query rows per workgroup = 4 waves x 16 NQB.  Five blocks per wave stream K/V a fifth less often
 // and measure about 4 % faster per row, but workgroups run in rounds of one per CU and a round
 // costs in proportion to NQB, so the choice goes by rounds x NQB (14B/720p: 46 x 4 + tail against
-// 37 x 5 x 0.96 + tail; 1.3B/480p: 6 x 4 against 5 x 5 x 0.96).  When the last round would hold only a few
-// workgroups, all of the last head, the main launch stops at the last full round and the
-// remaining query rows go to a second launch with one block per wave (64 rows per workgroup:
-// more, much shorter workgroups instead of a nearly empty full-length round; 14B/720p: 8 workgroups
-// of 320 rows become 37 of 64, 77.4 -> 76.1 ms per launch).
+// 37 x 5 x 0.96 + tail; 1.3B/480p: 6 x 4 against 5 x 5 x 0.96).  A call becomes TWO launches when its
+// last round would be poorly filled:
+//  * few workgroups left, all of the last head: the main launch stops at the last full round and
+//    the remaining query rows of that head go to a launch with one block per wave (64 rows per
+//    workgroup: more, much shorter workgroups instead of a nearly empty full-length round;
+//    14B/720p: 8 workgroups of 320 rows become 37 of 64, 77.4 -> 76.1 ms per call);
+//  * otherwise, when it pays by the same cost model: the query ROWS are split -- rows [0, row0) of
+//    every head in full rounds of the main block count, the rest of every head with four blocks or
+//    one block per wave.  This is the case of launches with few heads (a head chunk of a
+//    sequence-parallel rank: 5 heads x 75 600 rows = 4.63 rounds of 320-row workgroups become 4
+//    full rounds + one round of 256-row workgroups).
 // Options attn_qb = 4|5 fix NQB and attn_tail = 0 keeps everything in one launch (A/B switches).
+namespace {
+
+// rows [row0, row1) of every head (or of the last head only) with `m` blocks per wave
+int launch_rows(const lx2v_attn::AttnParams& p, int64_t row0, int64_t row1, int m, bool last_head_only, hipStream_t st, const char* what) {
+  lx2v_attn::AttnParams pp = p;
+  const int64_t h0 = last_head_only ? p.heads - 1 : 0;
+  pp.q = p.q + row0 * p.ldq + h0 * HD;
+  pp.out = p.out + row0 * p.ldo + h0 * HD;
+  pp.k = p.k + h0 * HD;
+  pp.v = p.v + h0 * HD;
+  pp.heads = last_head_only ? 1 : p.heads;
+  pp.sq = (int)(row1 - row0);
+  pp.nqb = (int)((pp.sq + 64 * m - 1) / (64 * m));
+  const int64_t nwg = (int64_t)pp.nqb * pp.heads;
+  if (nwg == 0) return LX2V_OK;
+  switch (m) {
+    case 5: return launch_with_rounds(attn_fwd_x16_kernel<true, 5>, attn_fwd_x16_kernel<false, 5>, X16_THREADS, pp, nwg, st, what);
+    case 4: return launch_with_rounds(attn_fwd_x16_kernel<true, 4>, attn_fwd_x16_kernel<false, 4>, X16_THREADS, pp, nwg, st, what);
+    default: return launch_with_rounds(attn_fwd_x16_kernel<true, 1>, attn_fwd_x16_kernel<false, 1>, X16_THREADS, pp, nwg, st, what);
+  }
+}
+
+}  // namespace
+
 int lx2v_attn_launch_x16(const lx2v_attn::AttnParams& p, hipStream_t st) {
   static int cus_cached[64];
   int dev = 0, cus = 256;
@@ -510,41 +540,60 @@ int lx2v_attn_launch_x16(const lx2v_attn::AttnParams& p, hipStream_t st) {
     cus = cus_cached[dev];
   }
   auto blocks = [&](int m) { return (int64_t)((p.sq + 64 * m - 1) / (64 * m)); };
-  // the workgroups of a last round that is worth a second launch: few (one round of 64-row
+  auto rounds = [&](int64_t wgs) { return (double)((wgs + cus - 1) / cus); };
+  // cost of one round in units of "64 rows per wave": m blocks cost m (0.96 m for m = 5, about 1.3
+  // for m = 1, whose workgroups spend relatively more on their prologue); a second launch adds 0.15
+  auto per_round = [](int m) { return m == 5 ? 4.8 : m == 4 ? 4.0 : 1.3; };
+  // the workgroups of a last round that is worth a launch of their own: few (one round of 64-row
   // workgroups takes their rows) and all of the last head
   auto tail_of = [&](int m) -> int64_t {
     const int64_t wgs = blocks(m) * p.heads, rest = wgs % cus;
     return (wgs > cus && rest > 0 && rest <= blocks(m) && rest * m <= cus) ? rest : 0;
   };
   const bool tail_on = lx2v_options().attn_tail != 0;
-  // cost in units of "one round of 64 rows per wave": a round of m blocks costs m (0.96 m for
-  // m = 5), a tail launch about 1.3
-  auto cost = [&](int m) {
-    const int64_t wgs = blocks(m) * p.heads;
-    const double per_round = m == 5 ? 0.96 * m : (double)m;
-    if (tail_on && tail_of(m) > 0) return (double)(wgs / cus) * per_round + 1.3;
-    return (double)((wgs + cus - 1) / cus) * per_round;
+  struct Plan {
+    int m, t;            // blocks per wave of the main launch / of the second launch (0: none)
+    int64_t row0;        // first row of the second launch
+    bool last_head_only; // the second launch covers the last head only
+    double cost;
   };
-  int nqb_wave = cost(5) < cost(4) ? 5 : 4;
-  if (lx2v_options().attn_qb != 0) nqb_wave = lx2v_options().attn_qb;
-  lx2v_attn::AttnParams pp = p;
-  pp.nqb = (int)blocks(nqb_wave);
-  int64_t nwg = (int64_t)pp.nqb * p.heads;
-  const int64_t rest = tail_on ? tail_of(nqb_wave) : 0;
-  const bool split = rest > 0;
-  nwg -= rest;
-  const int rc = nqb_wave == 5 ? launch_with_rounds(attn_fwd_x16_kernel<true, 5>, attn_fwd_x16_kernel<false, 5>, X16_THREADS, pp, nwg, st, "attn_fwd(x16)")
+  auto plan_for = [&](int m) {
+    const int64_t nb = blocks(m), wgs = nb * p.heads;
+    Plan best{m, 0, p.sq, false, rounds(wgs) * per_round(m)};
+    if (!tail_on || wgs <= cus) return best;
+    if (const int64_t rest = tail_of(m); rest > 0) {
+      const Plan c{m, 1, (nb - rest) * 64 * m, true, (double)(wgs / cus) * per_round(m) + 1.3};
+      if (c.cost < best.cost) best = c;
+      return best;  // (the measured case: kept as it is)
+    }
+    // rows split: `full` full rounds of the main block count, the other rows of every head behind them
+    const int64_t full = wgs / cus, nb_main = full * cus / p.heads;
+    if (nb_main > 0 && nb_main < nb) {
+      const int64_t row0 = nb_main * 64 * m, rest_rows = p.sq - row0;
+      for (int t : {4, 1}) {
+        if (t == m) continue;
+        const int64_t twgs = (rest_rows + 64 * t - 1) / (64 * t) * p.heads;
+        const Plan c{m, t, row0, false, rounds(nb_main * p.heads) * per_round(m) + rounds(twgs) * per_round(t) + 0.15};
+        if (c.cost < 0.99 * best.cost) best = c;
+      }
+    }
+    return best;
+  };
+  Plan plan = plan_for(5);
+  if (const Plan p4 = plan_for(4); p4.cost < plan.cost) plan = p4;
+  if (lx2v_options().attn_qb != 0) plan = plan_for(lx2v_options().attn_qb);
+  if (plan.t == 0) return launch_rows(p, 0, p.sq, plan.m, false, st, "attn_fwd(x16)");
+  if (plan.last_head_only) {
+    // every head but the last in full, the last head up to row0; then the last head's remaining rows
+    lx2v_attn::AttnParams pp = p;
+    pp.nqb = (int)blocks(plan.m);
+    const int64_t nwg = (int64_t)pp.nqb * p.heads - tail_of(plan.m);
+    const int rc = plan.m == 5 ? launch_with_rounds(attn_fwd_x16_kernel<true, 5>, attn_fwd_x16_kernel<false, 5>, X16_THREADS, pp, nwg, st, "attn_fwd(x16)")
                                : launch_with_rounds(attn_fwd_x16_kernel<true, 4>, attn_fwd_x16_kernel<false, 4>, X16_THREADS, pp, nwg, st, "attn_fwd(x16)");
-  if (rc != LX2V_OK || !split) return rc;
-  // the last `rest` query blocks of the last head
-  const int64_t row0 = (int64_t)(pp.nqb - rest) * 64 * nqb_wave;
-  lx2v_attn::AttnParams pt = p;
-  pt.q = p.q + row0 * p.ldq + (int64_t)(p.heads - 1) * HD;
-  pt.out = p.out + row0 * p.ldo + (int64_t)(p.heads - 1) * HD;
-  pt.k = p.k + (int64_t)(p.heads - 1) * HD;
-  pt.v = p.v + (int64_t)(p.heads - 1) * HD;
-  pt.heads = 1;
-  pt.sq = (int)(p.sq - row0);
-  pt.nqb = (pt.sq + 63) / 64;
-  return launch_with_rounds(attn_fwd_x16_kernel<true, 1>, attn_fwd_x16_kernel<false, 1>, X16_THREADS, pt, (int64_t)pt.nqb, st, "attn_fwd(x16 tail)");
+    if (rc != LX2V_OK) return rc;
+    return launch_rows(p, plan.row0, p.sq, 1, true, st, "attn_fwd(x16 tail)");
+  }
+  const int rc = launch_rows(p, 0, plan.row0, plan.m, false, st, "attn_fwd(x16)");
+  if (rc != LX2V_OK) return rc;
+  return launch_rows(p, plan.row0, p.sq, plan.t, false, st, "attn_fwd(x16 rows tail)");
 }

@@ -72,6 +72,28 @@ def test_round_alignment_and_launch_split_do_not_change_results(case, options):
     assert (one.float() - base.float()).abs().max().item() <= 2e-3   # same rows by 64-row workgroups: other rescale points only
 
 
+def test_row_split_of_a_launch_with_few_heads(case, options):
+    """A head chunk of a sequence-parallel rank: 5 heads x 75 600 rows = 4.63 rounds of 320-row
+    workgroups.  The launch plan runs rows [0, 65 280) of every head in four full rounds and the other
+    10 320 rows of every head as 256-row workgroups in a second launch; one launch (attn_tail = 0)
+    computes the same rows with 320-row workgroups."""
+    q, k, v, rows, ref = case
+    q5, k5, v5 = q[:, :5], k[:, :5], v[:, :5]
+    row0 = 204 * 320
+    options(attn_kernel=16, attn_qb=0, attn_tail=1)
+    base = hip.attn_fwd(q5, k5, v5)
+    options(attn_tail=0)
+    one = hip.attn_fwd(q5, k5, v5)
+    assert torch.equal(one[:row0], base[:row0])           # the main launch is the same arithmetic
+    assert not torch.equal(one[row0:], base[row0:])       # the second launch is live (other block count, other rescale points)
+    assert (one.float() - base.float()).abs().max().item() <= 2e-3
+    pick = torch.cat([rows, torch.tensor([row0 - 1, row0, row0 + 255, row0 + 256, S - 1])]).unique()
+    want = R.sdpa(q5[pick.to(q.device)].float().cpu(), k5.float().cpu(), v5.float().cpu())
+    got = base[pick.to(base.device)].float().cpu()
+    assert cos(got, want) >= 0.9999
+    assert torch.nn.functional.cosine_similarity(got, want, dim=1).min().item() >= 0.999
+
+
 def test_w4_kernel_at_full_length(case, options):
     q, k, v, rows, ref = case
     options(attn_kernel=4)

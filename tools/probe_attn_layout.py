@@ -73,3 +73,24 @@ for rep in range(int(os.environ.get("REPS", 4))):
         res[name].append(e0.elapsed_time(e1) / 2)
 for name, v in res.items():
     print(f"{name:32s} " + " ".join(f"{x:7.2f}" for x in v) + f"   min {min(v):.2f} ms = {4.0 * S * S * H * d / min(v) / 1e9:.0f} TFLOP/s", flush=True)
+
+
+# ---- launches with few heads (head chunks of a sequence-parallel rank): one launch against the two-launch plan ----
+for heads in (2, 3, 5, 10, 20, 40):
+    qs, ks, vs = (cols(qkv, i, 0, heads, H) for i in range(3))
+    line = f"{heads:2d} heads:"
+    for tail in (0, 1):
+        hip.set_option("attn_tail", tail)
+        hip.attn_fwd(qs, ks, vs)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            hip.attn_fwd(qs, ks, vs)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        line += f"   attn_tail={tail}: {min(ts):7.3f} ms ({4.0 * S * S * heads * d / min(ts) / 1e9:5.0f} TFLOP/s)"
+    print(line, flush=True)
+hip.set_option("attn_tail", 1)
