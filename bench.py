@@ -387,6 +387,12 @@ def main():
                          "prices what the N > 1 path costs besides the links")
     args = ap.parse_args()
 
+    # stdout carries the one JSON line and nothing else: libraries that print to file descriptor 1 (RCCL's
+    # version banner at communicator creation) are sent to stderr for the whole run
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     if os.environ.get("LX2V_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit after N seconds
         import faulthandler
 
@@ -428,7 +434,7 @@ def main():
     if args.model in HY_MODELS:
         line = run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu)
         if rank == 0:
-            print(json.dumps(line), flush=True)
+            print(json.dumps(line), file=json_out, flush=True)
         if world > 1 or args.sp1:
             dist.barrier()
             dist.destroy_process_group()
@@ -563,7 +569,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
             line["cpu_baseline"] = cpu_baseline(D, H, F, S, layers, threads)
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=json_out, flush=True)
     if world > 1 or args.sp1:
         dist.barrier()
         dist.destroy_process_group()
