@@ -219,6 +219,10 @@ def attn_peak(args):
 
 def arithmetic_label(args):
     """The JSON line's `dtype` and the metric-name suffix for the non-headline arithmetic choices."""
+    if args.residual == "fp32":
+        base = argparse.Namespace(**dict(vars(args), residual="bf16"))
+        d, suffix = arithmetic_label(base)
+        return d + " + fp32 residual stream", (suffix[:-1] + ", fp32 residual stream)") if suffix else " (fp32 residual stream)"
     if args.linear == "bf16" and args.attn == "bf16":
         return "bf16", ""
     lin = "bf16 Linears" if args.linear == "bf16" else "fp8 Linears (W8A8 e4m3)"
@@ -233,6 +237,8 @@ def run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu):
     import lightx2v_amd as L
     from lightx2v_amd import ulysses
 
+    if args.residual != "bf16":
+        raise SystemExit("--residual fp32 is built for the Wan blocks")
     D, H, F, layers = HY_MODELS[args.model]
     if args.layers is not None:
         layers = args.layers
@@ -380,6 +386,8 @@ def main():
                     help="arithmetic of the blocks' Linears: bf16 (the headline configuration) or W8A8 e4m3 (the reference's fp8 schemes)")
     ap.add_argument("--attn", default="bf16", choices=["bf16", "fp8"],
                     help="self-attention arithmetic: bf16 (the headline configuration) or block-scaled e4m3 on the fp8 MFMA (where the reference would run a quantised backend)")
+    ap.add_argument("--residual", default="bf16", choices=["bf16", "fp32"],
+                    help="storage of the residual stream between the Linears: bf16 (the headline configuration) or fp32 (the reference's SENSITIVE_LAYER_DTYPE=FP32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sp1", action="store_true",
                     help="one GPU only: run the sequence-parallel code path on an RCCL group of ONE rank (pack kernel, chunked attention, "
@@ -457,6 +465,7 @@ def main():
            "sample_guide_scale": GUIDE_SCALE, "enable_cfg": True, "run_device": "cuda",
            "dit_quant_scheme": "hip-bf16" if args.linear == "bf16" else "hip-fp8",
            "self_attn_1_type": "hip_flash_attn" if args.attn == "bf16" else "hip_fp8_attn",
+           "sensitive_layer_dtype": "fp32" if args.residual == "fp32" else "bf16",
            "cfg_parallel": cfg_p > 1, "cfg_p_group": cfg_group,
            "seq_parallel": seq_p > 1 or args.sp1, "seq_p_group": seq_group, "parallel": {"seq_p_size": seq_p, "cfg_p_size": cfg_p, "seq_p_attn_type": "hip_ulysses"}}
     moe = args.model == "wan2.2-i2v-a14b"
@@ -545,7 +554,7 @@ def main():
     exposed_ms = ulysses.COMM_TIMER.total_ms() / args.steps if (world > 1 or args.sp1) else 0.0
     if rank == 0:
         line = {
-            "metric": "s/denoise-step Wan2.1-T2V-14B 720p81f" if (args.model, args.res, args.linear, args.attn) == ("wan2.1-t2v-14b", "720p", "bf16", "bf16") else f"s/denoise-step {args.model} {args.res}81f" + arithmetic_label(args)[1],
+            "metric": "s/denoise-step Wan2.1-T2V-14B 720p81f" if (args.model, args.res, args.linear, args.attn, args.residual) == ("wan2.1-t2v-14b", "720p", "bf16", "bf16", "bf16") else f"s/denoise-step {args.model} {args.res}81f" + arithmetic_label(args)[1],
             "value": s_per_step, "unit": "s/denoise-step", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": s_per_step * 1e3, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
             "dtype": arithmetic_label(args)[0], "data": "synthetic latents and text features, random-init weights of the named architecture"

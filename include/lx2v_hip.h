@@ -107,6 +107,22 @@ int lx2v_gate_residual_rows_bf16(uint16_t* x, int64_t ldx, const uint16_t* y, in
                                  const float* gate, const uint16_t* gate_rows, int64_t ld_rows,
                                  int64_t rows, int dim, void* stream);
 
+/* ---- the residual stream kept in fp32 --------------------------------------------------------
+ * The reference's SENSITIVE_LAYER_DTYPE=FP32 mode holds x in fp32 between the Linears: the three
+ * residual sums upcast (`x.to(fp32) + y.to(fp32) * gate`), the norms read fp32 and their modulated
+ * result is cast back to the compute dtype for the next Linear
+ *                 lightx2v/models/networks/wan/infer/transformer_infer.py:86-90, 150-160, 209-213, 289-299, 312-316
+ *                 lightx2v/utils/envs.py:39-43.
+ * lx2v_ln_modulate_f32in: lx2v_ln_modulate_rows_bf16 with fp32 rows x (scale_rows / shift_rows may be
+ * NULL: vector modulation only); bf16 out.  lx2v_gate_residual_f32: x (fp32) += y (bf16) * (gate +
+ * gate_rows[r, :]), gate / gate_rows optional as in the bf16 entry points. */
+int lx2v_ln_modulate_f32in(const float* x, int64_t ldx, const float* ln_w, const float* ln_b,
+                           const float* scale, const float* shift, const uint16_t* scale_rows,
+                           const uint16_t* shift_rows, int64_t ld_rows, uint16_t* out, int64_t ldo,
+                           int64_t rows, int dim, float eps, void* stream);
+int lx2v_gate_residual_f32(float* x, int64_t ldx, const uint16_t* y, int64_t ldy, const float* gate,
+                           const uint16_t* gate_rows, int64_t ld_rows, int64_t rows, int dim, void* stream);
+
 /* ---- GELU (tanh approximation), elementwise -------------------------------------------------
  * Replaces torch.nn.functional.gelu(approximate="tanh")  transformer_infer.py:305. */
 int lx2v_gelu_tanh_bf16(const uint16_t* x, uint16_t* out, int64_t n, void* stream);

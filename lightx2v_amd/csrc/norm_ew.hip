@@ -27,15 +27,35 @@ LX2V_DEVICE void load_row(const uint16_t* __restrict__ p, int nchunks, int lane,
   }
 }
 
+// the same row from fp32 storage (the residual stream kept in fp32): chunk = 8 floats = two 16-byte loads
+template <int NC>
+LX2V_DEVICE void load_row_f32(const float* __restrict__ p, int nchunks, int lane, RowRegs<NC>& r) {
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int ch = lane + 64 * c;
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+    if (ch < nchunks) {
+      lo = *reinterpret_cast<const f32x4*>(p + (int64_t)ch * 8);
+      hi = *reinterpret_cast<const f32x4*>(p + (int64_t)ch * 8 + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      r.f[c][i] = lo[i];
+      r.f[c][4 + i] = hi[i];
+    }
+  }
+}
+
 // out = (LN(x) * w + b) * (1 + scale) + shift
 // Q8: the bf16-rounded result is not written; the row is quantised to OCP e4m3 with one scale per
 // row (qscale[row] = max|row| / 448, out8 = row / qscale) while it is still in registers -- the
 // bytes and scales are those the row-wise quantisation kernel produces from the bf16 output.  This
 // file is built with fast-math, so the two quotients are formed in double precision and rounded
 // once: that is the correctly rounded single-precision quotient.
-template <int NC, bool Q8>
+// XF32: x holds fp32 rows (row stride ldx in elements) instead of bf16.
+template <int NC, bool Q8, bool XF32 = false>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(
-    const uint16_t* __restrict__ x, int64_t ldx, const float* __restrict__ ln_w,
+    const void* __restrict__ x, int64_t ldx, const float* __restrict__ ln_w,
     const float* __restrict__ ln_b, const float* __restrict__ scale, const float* __restrict__ shift,
     const uint16_t* __restrict__ scale_rows, const uint16_t* __restrict__ shift_rows, int64_t ld_rows,
     uint16_t* __restrict__ out, int64_t ldo, int64_t rows, int dim, float eps, uint8_t* __restrict__ out8, float* __restrict__ qscale) {
@@ -44,7 +64,8 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(
   if (row >= rows) return;
   const int nchunks = dim >> 3;
   RowRegs<NC> r;
-  load_row<NC>(x + row * ldx, nchunks, lane, r);
+  if constexpr (XF32) load_row_f32<NC>(static_cast<const float*>(x) + row * ldx, nchunks, lane, r);
+  else load_row<NC>(static_cast<const uint16_t*>(x) + row * ldx, nchunks, lane, r);
 
   float s = 0.f;
 #pragma unroll
@@ -323,12 +344,13 @@ int ew_grid(int64_t work_items) {
 namespace {
 template <int NC> constexpr auto ln_modulate_bf16_kernel = ln_modulate_kernel<NC, false>;
 template <int NC> constexpr auto ln_modulate_q8_kernel = ln_modulate_kernel<NC, true>;
+template <int NC> constexpr auto ln_modulate_f32in_kernel = ln_modulate_kernel<NC, false, true>;
 }  // namespace
 
 // out8 == NULL: bf16 rows to `out`; otherwise e4m3 rows to `out8` (row stride ldo, in bytes) and their scales to `qscale`.
-static int ln_modulate_launch(const uint16_t* x, int64_t ldx, const float* ln_w, const float* ln_b, const float* scale, const float* shift,
+static int ln_modulate_launch(const void* x, int64_t ldx, const float* ln_w, const float* ln_b, const float* scale, const float* shift,
                               const uint16_t* scale_rows, const uint16_t* shift_rows, int64_t ld_rows, uint16_t* out, int64_t ldo,
-                              int64_t rows, int dim, float eps, void* stream, uint8_t* out8 = nullptr, float* qscale = nullptr) {
+                              int64_t rows, int dim, float eps, void* stream, uint8_t* out8 = nullptr, float* qscale = nullptr, bool x_f32 = false) {
   LX2V_REQUIRE(rows == 0 || (x && (out || (out8 && qscale))), LX2V_EINVAL, "ln_modulate: null tensor");
   LX2V_REQUIRE(rows >= 0 && dim > 0, LX2V_EINVAL, "ln_modulate: bad shape rows=%lld dim=%d", (long long)rows, dim);
   LX2V_REQUIRE(dim % 8 == 0 && dim <= 8192, LX2V_EUNSUP, "ln_modulate: dim=%d must be a multiple of 8 and <= 8192", dim);
@@ -342,7 +364,10 @@ static int ln_modulate_launch(const uint16_t* x, int64_t ldx, const float* ln_w,
   if (rows == 0) return LX2V_OK;
   const dim3 grid((unsigned)((rows + kRowsPerBlock - 1) / kRowsPerBlock)), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (out8 == nullptr) {
+  if (x_f32) {
+    LX2V_REQUIRE(out8 == nullptr, LX2V_EUNSUP, "ln_modulate: fp32 rows are not combined with the e4m3 output");
+    DISPATCH_NC(pick_nc(dim), ln_modulate_f32in_kernel, x, ldx, ln_w, ln_b, scale, shift, scale_rows, shift_rows, ld_rows, out, ldo, rows, dim, eps, out8, qscale);
+  } else if (out8 == nullptr) {
     DISPATCH_NC(pick_nc(dim), ln_modulate_bf16_kernel, x, ldx, ln_w, ln_b, scale, shift, scale_rows, shift_rows, ld_rows, out, ldo, rows, dim, eps, out8, qscale);
   } else {
     DISPATCH_NC(pick_nc(dim), ln_modulate_q8_kernel, x, ldx, ln_w, ln_b, scale, shift, scale_rows, shift_rows, ld_rows, out, ldo, rows, dim, eps, out8, qscale);
@@ -363,6 +388,12 @@ extern "C" int lx2v_ln_modulate_rows_bf16(const uint16_t* x, int64_t ldx, const 
                                           int64_t rows, int dim, float eps, void* stream) {
   LX2V_REQUIRE(scale_rows != nullptr, LX2V_EINVAL, "ln_modulate_rows: per-token rows are NULL");
   return ln_modulate_launch(x, ldx, ln_w, ln_b, scale, shift, scale_rows, shift_rows, ld_rows, out, ldo, rows, dim, eps, stream);
+}
+
+extern "C" int lx2v_ln_modulate_f32in(const float* x, int64_t ldx, const float* ln_w, const float* ln_b, const float* scale, const float* shift,
+                                      const uint16_t* scale_rows, const uint16_t* shift_rows, int64_t ld_rows, uint16_t* out, int64_t ldo,
+                                      int64_t rows, int dim, float eps, void* stream) {
+  return ln_modulate_launch(x, ldx, ln_w, ln_b, scale, shift, scale_rows, shift_rows, ld_rows, out, ldo, rows, dim, eps, stream, nullptr, nullptr, true);
 }
 
 extern "C" int lx2v_ln_modulate_quant_fp8(const uint16_t* x, int64_t ldx, const float* ln_w, const float* ln_b,
@@ -395,6 +426,62 @@ extern "C" int lx2v_rmsnorm_rope_bf16(const uint16_t* x, int64_t ldx, const floa
   hipStream_t st = (hipStream_t)stream;
   DISPATCH_NC(pick_nc(dim), rmsnorm_rope_kernel, x, ldx, w, do_norm, rope_cos_sin, head_dim, out, ldo, rows, dim, eps);
   LX2V_CHECK_LAUNCH("rmsnorm_rope");
+  return LX2V_OK;
+}
+
+// x (fp32 rows) += y (bf16 rows) * gate: the residual stream kept in fp32.  Product and sum are
+// two roundings, as x.float() + y.float() * gate evaluates.
+__global__ __launch_bounds__(256) void gate_residual_f32_kernel(float* __restrict__ x, int64_t ldx, const uint16_t* __restrict__ y, int64_t ldy,
+                                                                const float* __restrict__ gate, const uint16_t* __restrict__ gate_rows, int64_t ld_rows,
+                                                                int64_t rows, int dim) {
+  const int nchunks = dim >> 3;
+  const int64_t total = rows * nchunks;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / nchunks;
+    const int col = (int)(i - row * nchunks) * 8;
+    float* xp = x + row * ldx + col;
+    f32x4 a0 = *reinterpret_cast<const f32x4*>(xp), a1 = *reinterpret_cast<const f32x4*>(xp + 4);
+    float b[8];
+    unpack8(*reinterpret_cast<const u32x4*>(y + row * ldy + col), b);
+    if (gate != nullptr) {
+      f32x4 g0 = *reinterpret_cast<const f32x4*>(gate + col), g1 = *reinterpret_cast<const f32x4*>(gate + col + 4);
+      if (gate_rows != nullptr) {
+        float gr[8];
+        unpack8(*reinterpret_cast<const u32x4*>(gate_rows + row * ld_rows + col), gr);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          g0[j] += gr[j];
+          g1[j] += gr[j + 4];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a0[j] += __fmul_rn(b[j], g0[j]);
+        a1[j] += __fmul_rn(b[j + 4], g1[j]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a0[j] += b[j];
+        a1[j] += b[j + 4];
+      }
+    }
+    *reinterpret_cast<f32x4*>(xp) = a0;
+    *reinterpret_cast<f32x4*>(xp + 4) = a1;
+  }
+}
+
+extern "C" int lx2v_gate_residual_f32(float* x, int64_t ldx, const uint16_t* y, int64_t ldy, const float* gate, const uint16_t* gate_rows,
+                                      int64_t ld_rows, int64_t rows, int dim, void* stream) {
+  LX2V_REQUIRE(rows == 0 || (x && y), LX2V_EINVAL, "gate_residual_f32: null tensor");
+  LX2V_REQUIRE(rows >= 0 && dim > 0 && dim % 8 == 0, LX2V_EINVAL, "gate_residual_f32: dim=%d must be a positive multiple of 8", dim);
+  LX2V_REQUIRE(ldx % 4 == 0 && ldy % 8 == 0 && ldx >= dim && ldy >= dim, LX2V_EINVAL, "gate_residual_f32: row strides must be multiples of 4 (x) / 8 (y) and >= dim");
+  LX2V_REQUIRE(lx2v_aligned16(x) && lx2v_aligned16(y), LX2V_EINVAL, "gate_residual_f32: tensors must be 16-byte aligned");
+  LX2V_REQUIRE(gate_rows == nullptr || (gate != nullptr && ld_rows % 8 == 0 && ld_rows >= dim && lx2v_aligned16(gate_rows)), LX2V_EINVAL,
+               "gate_residual_f32: per-token rows need the gate vector, 16-byte alignment and a row stride that is a multiple of 8 and >= dim");
+  if (rows == 0) return LX2V_OK;
+  hipLaunchKernelGGL(gate_residual_f32_kernel, dim3(ew_grid(rows * (dim >> 3))), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, gate, gate_rows, ld_rows, rows, dim);
+  LX2V_CHECK_LAUNCH("gate_residual_f32");
   return LX2V_OK;
 }
 

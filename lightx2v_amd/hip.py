@@ -15,7 +15,7 @@ from typing import Optional
 import torch
 
 _LIB_NAME = "liblx2v_hip.so"
-ABI_VERSION = 2  # include/lx2v_hip.h: lx2v_abi_version()
+ABI_VERSION = 3  # include/lx2v_hip.h: lx2v_abi_version()
 _lib: Optional[ctypes.CDLL] = None
 
 EPI_NONE, EPI_GELU_TANH, EPI_RESIDUAL = 0, 1, 2
@@ -29,6 +29,8 @@ _SIGNATURES = {
     "lx2v_ln_modulate_rows_bf16": [_P, _I64, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I64, _I, _F, _P],
     "lx2v_ln_modulate_quant_fp8": [_P, _I64, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _I64, _I, _F, _P],
     "lx2v_gate_residual_rows_bf16": [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I, _P],
+    "lx2v_ln_modulate_f32in": [_P, _I64, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I64, _I, _F, _P],
+    "lx2v_gate_residual_f32": [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I, _P],
     "lx2v_gelu_tanh_bf16": [_P, _P, _I64, _P],
     "lx2v_gelu_erf_bf16": [_P, _P, _I64, _P],
     "lx2v_gemm_bf16": [_P, _I64, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _I64, _I, _P, _I64, _P, _P],
@@ -118,6 +120,14 @@ def _need_bf16_cuda(name: str, t: torch.Tensor, inner_contig: bool = True):
         raise Lx2vError(f"{name}: innermost dimension must be contiguous")
 
 
+def _need_f32_rows(name: str, t: torch.Tensor):
+    if not t.is_cuda:
+        raise Lx2vError(f"{name}: expected a GPU tensor, got device {t.device} (no CPU fallback exists)")
+    if t.dtype != torch.float32 or t.dim() != 2 or t.stride(-1) != 1 or t.stride(0) % 8 != 0 or t.data_ptr() % 16 != 0:
+        raise Lx2vError(f"{name}: expected fp32 [rows, dim] with a contiguous innermost dimension, a row stride multiple of 8 and a 16-byte aligned base, "
+                        f"got {t.dtype} {tuple(t.shape)} stride {t.stride()}")
+
+
 def _need_out(name: str, t: torch.Tensor, shape, like: torch.Tensor, dtype=torch.bfloat16):
     """A caller-supplied output / residual slot: same device as the input, exact shape and dtype,
     contiguous innermost dimension (rows may be strided: the slots are often views)."""
@@ -188,7 +198,11 @@ def ln_modulate(x: torch.Tensor, ln_w=None, ln_b=None, scale=None, shift=None, e
     """`scale` / `shift`: fp32 [dim] vectors, or both `RowMod` (per-token modulation).
     `quant`: return the result as `QuantRows` (e4m3 rows + per-row scales, the values
     `quant_fp8_rowwise` gives for the bf16 result) instead of a bf16 tensor."""
-    _need_bf16_cuda("ln_modulate.x", x)
+    x_f32 = x.dtype == torch.float32   # the residual stream kept in fp32 (the reference's SENSITIVE_LAYER_DTYPE=FP32)
+    if x_f32:
+        _need_f32_rows("ln_modulate.x", x)
+    else:
+        _need_bf16_cuda("ln_modulate.x", x)
     assert x.dim() == 2
     rows, dim = x.shape
     w = _vec_f32("ln_w", ln_w, dim, x)
@@ -201,6 +215,8 @@ def ln_modulate(x: torch.Tensor, ln_w=None, ln_b=None, scale=None, shift=None, e
         sh, sh_rows = shift.checked("shift", rows, dim, x)
         if sc_rows.stride(0) != sh_rows.stride(0):
             raise Lx2vError("ln_modulate: per-token scale and shift rows must share one row stride")
+    if quant and x_f32:
+        raise Lx2vError("ln_modulate: fp32 rows are not combined with the e4m3 output")
     if quant:
         if out is not None:
             raise Lx2vError("ln_modulate: `out` and `quant` exclude each other")
@@ -213,9 +229,16 @@ def ln_modulate(x: torch.Tensor, ln_w=None, ln_b=None, scale=None, shift=None, e
         _check(st, "lx2v_ln_modulate_quant_fp8")
         return QuantRows(q, qs)
     if out is None:
-        out = torch.empty((rows, dim), dtype=x.dtype, device=x.device)
+        out = torch.empty((rows, dim), dtype=torch.bfloat16, device=x.device)
     else:
         _need_out("ln_modulate.out", out, (rows, dim), x)
+    if x_f32:
+        if not per_token:
+            sc, sh, sc_rows, sh_rows = _vec_f32("scale", scale, dim, x), _vec_f32("shift", shift, dim, x), None, None
+        st = load().lx2v_ln_modulate_f32in(x.data_ptr(), x.stride(0), _ptr(w), _ptr(b), _ptr(sc), _ptr(sh), _ptr(sc_rows), _ptr(sh_rows),
+                                            0 if sc_rows is None else sc_rows.stride(0), out.data_ptr(), out.stride(0), rows, dim, eps, _stream())
+        _check(st, "lx2v_ln_modulate_f32in")
+        return out
     if per_token:
         st = load().lx2v_ln_modulate_rows_bf16(x.data_ptr(), x.stride(0), _ptr(w), _ptr(b), _ptr(sc), _ptr(sh), sc_rows.data_ptr(), sh_rows.data_ptr(),
                                                 sc_rows.stride(0), out.data_ptr(), out.stride(0), rows, dim, eps, _stream())
@@ -253,10 +276,18 @@ def rmsnorm_rope(x: torch.Tensor, weight=None, rope_cos_sin: Optional[torch.Tens
 
 
 def gate_residual_(x: torch.Tensor, y: torch.Tensor, gate=None) -> torch.Tensor:
-    _need_bf16_cuda("gate_residual.x", x)
+    """x += y * gate in place; x is bf16, or fp32 (the residual stream kept in fp32) with y bf16."""
     _need_bf16_cuda("gate_residual.y", y)
     assert x.shape == y.shape and x.dim() == 2
     rows, dim = x.shape
+    if x.dtype == torch.float32:
+        _need_f32_rows("gate_residual.x", x)
+        g, g_rows = gate.checked("gate", rows, dim, x) if isinstance(gate, RowMod) else (_vec_f32("gate", gate, dim, x), None)
+        st = load().lx2v_gate_residual_f32(x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), _ptr(g), _ptr(g_rows),
+                                            0 if g_rows is None else g_rows.stride(0), rows, dim, _stream())
+        _check(st, "lx2v_gate_residual_f32")
+        return x
+    _need_bf16_cuda("gate_residual.x", x)
     if isinstance(gate, RowMod):
         g, g_rows = gate.checked("gate", rows, dim, x)
         st = load().lx2v_gate_residual_rows_bf16(x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), _ptr(g), g_rows.data_ptr(), g_rows.stride(0), rows, dim, _stream())

@@ -256,7 +256,7 @@ class HipMMWeight:
         input's K columns are stored as segments, `input_tensor` being the rows of the first one.
         A per-token gate (hip.RowMod) does not fit the GEMM epilogue's [N] gate vector: the product is
         formed first and the gated add is its own pass."""
-        if isinstance(gate, hip.RowMod):
+        if isinstance(gate, hip.RowMod) or resid.dtype == torch.float32:   # (an fp32 residual stream is not the epilogue's bf16 slot either)
             return hip.gate_residual_(resid, hip.gemm(input_tensor, self.weight_nk, self.bias, kseg=kseg), gate)
         return hip.gemm(input_tensor, self.weight_nk, self.bias, epilogue=hip.EPI_RESIDUAL, resid=resid, gate=gate, out=resid, kseg=kseg)
 
@@ -344,7 +344,7 @@ class HipFp8MMWeight(HipMMWeight):
     def apply_residual_(self, input_tensor, resid, gate=None, kseg=None):
         if kseg is not None:
             raise NotImplementedError("hip-fp8: K-segmented operands are built for the bf16 scheme only")
-        if isinstance(gate, hip.RowMod):  # per-token gate: product first, gated add as its own pass
+        if isinstance(gate, hip.RowMod) or resid.dtype == torch.float32:  # per-token gate / fp32 residual stream: product first, gated add as its own pass
             return hip.gate_residual_(resid, self._run(input_tensor, hip.EPI_NONE), gate)
         return self._run(input_tensor, hip.EPI_RESIDUAL, resid=resid, gate=gate)
 
@@ -433,11 +433,13 @@ class HipLNWeight(_NormBase):
     def apply(self, input_tensor, quant_for=None):
         """`quant_for`: the matmul plugin(s) that alone consume the result; when they all take
         quantised rows (`accepts_quantized`), the result leaves the kernel as hip.QuantRows."""
-        return hip.ln_modulate(input_tensor, self.weight, self.bias, eps=self.eps, quant=_all_take_quantized(quant_for))
+        return hip.ln_modulate(input_tensor, self.weight, self.bias, eps=self.eps, quant=_all_take_quantized(quant_for) and input_tensor.dtype != torch.float32)
 
     def apply_modulate(self, input_tensor, scale, shift, quant_for=None):
-        """LN fused with `x * (1 + scale) + shift` (transformer_infer.py:12-13,154-157)."""
-        return hip.ln_modulate(input_tensor, self.weight, self.bias, scale, shift, eps=self.eps, quant=_all_take_quantized(quant_for))
+        """LN fused with `x * (1 + scale) + shift` (transformer_infer.py:12-13,154-157).  fp32 rows (the
+        residual stream kept in fp32) give a bf16 result; a W8A8 consumer then quantises it itself."""
+        return hip.ln_modulate(input_tensor, self.weight, self.bias, scale, shift, eps=self.eps,
+                               quant=_all_take_quantized(quant_for) and input_tensor.dtype != torch.float32)
 
 
 @RMS_WEIGHT_REGISTER("hip")

@@ -14,6 +14,7 @@ method for method.  Two execution modes share the same kernels:
 
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Any, Dict, Optional, Tuple
 
@@ -43,7 +44,22 @@ DEFAULTS = {
     "seq_parallel": False,
     "task": "t2v",
     "model_cls": "wan2.1",
+    # "fp32": the residual stream x stays in fp32 between the Linears (the reference's
+    # SENSITIVE_LAYER_DTYPE=FP32, lightx2v/utils/envs.py:39-43); None: read that environment variable
+    "sensitive_layer_dtype": None,
 }
+
+
+def sensitive_fp32(config) -> bool:
+    v = config.get("sensitive_layer_dtype")
+    if v is None:
+        v = os.environ.get("SENSITIVE_LAYER_DTYPE", "None")
+    v = str(v).lower()
+    if v in ("none", "bf16", "bfloat16"):
+        return False
+    if v in ("fp32", "float32"):
+        return True
+    raise ValueError(f"sensitive_layer_dtype={v!r}: 'fp32' or None (bf16) are built")
 
 
 def with_defaults(config: Dict[str, Any]) -> Dict[str, Any]:
@@ -179,6 +195,7 @@ class WanTransformerInfer:
         else:
             self.seq_p_group = None
             self.seq_p_fp8_comm = False
+        self.fp32_residual = sensitive_fp32(config)
         self.scheduler = _Scheduler()
         self.cos_sin: Optional[torch.Tensor] = None  # fp32 [S_local, head_dim] cos || sin
         self.block_idx = 0
@@ -199,6 +216,10 @@ class WanTransformerInfer:
 
     def infer_main_blocks(self, blocks, pre_infer_out):
         x = pre_infer_out.x
+        if self.fp32_residual and x.dtype != torch.float32:
+            # the reference upcasts at the first residual sum (transformer_infer.py:210-211); the first
+            # norm reads the same values either way
+            x = x.float()
         for block_idx in range(len(blocks)):
             self.block_idx = block_idx
             x = self.infer_block(blocks[block_idx], x, pre_infer_out)

@@ -32,9 +32,15 @@ def _residual(x, ori_x, holder):
     return hip.gate_residual_(x.clone(), ori_x, holder._minus_one)
 
 
+def _refuse_fp32_stream(runner):
+    if runner.fp32_residual:
+        raise NotImplementedError("feature caching keeps bf16 residuals of the block stack; it is not combined with sensitive_layer_dtype='fp32'")
+
+
 class WanTransformerInferTeaCaching(WanTransformerInfer):
     def __init__(self, config):
         super().__init__(config)
+        _refuse_fp32_stream(self)
         cfg = self.config
         self.teacache_thresh = cfg["teacache_thresh"]
         self.use_ret_steps = cfg["use_ret_steps"]
@@ -100,6 +106,7 @@ class WanTransformerInferTeaCaching(WanTransformerInfer):
 class WanTransformerInferMagCaching(WanTransformerInfer):
     def __init__(self, config):
         super().__init__(config)
+        _refuse_fp32_stream(self)
         cfg = self.config
         self.magcache_thresh = cfg["magcache_thresh"]
         self.K = cfg["magcache_K"]

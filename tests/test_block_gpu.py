@@ -66,6 +66,43 @@ def test_block_vs_reference_golden(cuda, name, mode):
     assert (got - ref).abs().max().item() <= 0.06 * max(1.0, ref.abs().max().item() / 4)
 
 
+@pytest.mark.parametrize("name", ["tiny_d256_g3x6x8", "small_d512_g3x5x7", "wan1p3b_g3x30x52", "wan14b_g3x30x52"])
+@pytest.mark.parametrize("fused", [True, False])
+def test_block_with_fp32_residual_stream(cuda, name, fused):
+    """`sensitive_layer_dtype: "fp32"` (the reference's SENSITIVE_LAYER_DTYPE=FP32): x stays in fp32
+    between the Linears, so the three bf16 roundings of the residual stream disappear.  The block
+    delta must then beat the floor ANY bf16 residual stream has, and the bf16 run of the same block."""
+    rec, c = cached_case(name)
+    W, inf = _build(c, cuda, fused_block=fused, sensitive_layer_dtype="fp32")
+    pre = _pre(c, cuda)
+    pre.x = c["x"].to(cuda)                 # fp32 rows, the oracle's own input
+    out = inf.infer_main_blocks(W.blocks, pre)
+    assert out.dtype == torch.float32 and out.data_ptr() == pre.x.data_ptr()
+    rows = golden_rows(rec, c["S"])
+    ref = torch.from_numpy(rec["x_out"])
+    got = out.cpu()[rows]
+    d32 = cos(got - c["x"][rows], ref - c["x"][rows])
+    # the same block with the bf16 stream
+    W2, inf2 = _build(c, cuda, fused_block=fused)
+    pre2 = _pre(c, cuda)
+    x_in = pre2.x.clone()
+    out2 = inf2.infer_block(W2.blocks[0], pre2.x, pre2)
+    d16 = cos(out2.float().cpu()[rows] - x_in.float().cpu()[rows], ref - c["x"][rows])
+    floor = _bf16_residual_floor(rec, c, rows)
+    print(f"\n{name} fused={fused}: delta cosine fp32 stream {d32:.6f}, bf16 stream {d16:.6f}, bf16-storage floor {floor:.6f}")
+    assert cos(got, ref) >= 0.99999
+    assert d32 >= 0.9995 and d32 > d16 and d32 > floor
+    # a bf16 input (what the pre-infer hands over) is upcast at the first block
+    pre3 = _pre(c, cuda)
+    out3 = inf.infer_main_blocks(W.blocks, pre3)
+    assert out3.dtype == torch.float32 and cos(out3.cpu()[rows], ref) >= 0.9999
+    # the head reads the fp32 stream
+    y = inf.infer_non_blocks(W, out, c["embed"].to(cuda))
+    assert y.dtype == torch.bfloat16 and y.shape == (c["S"], 64)
+    if "head_out" in rec.files:
+        assert cos(y.float().cpu()[rows], torch.from_numpy(rec["head_out"])) >= 0.9995
+
+
 @pytest.mark.parametrize("name", ["tiny_d256_g3x6x8", "wan1p3b_g3x6x8"])
 def test_head_vs_reference_golden(cuda, name):
     rec = load_golden(name)

@@ -85,6 +85,55 @@ def test_gate_residual_and_gelu(cuda, gated):
     assert (gout.float().cpu() - gref).abs().max().item() <= BF16_EPS * gref.abs().max().item() + 1e-3
 
 
+# ---- the residual stream kept in fp32 (the reference's SENSITIVE_LAYER_DTYPE=FP32) ----
+@pytest.mark.parametrize("rows,dim", [(1, 64), (7, 256), (130, 1536), (33, 5120), (5, 8192)])
+@pytest.mark.parametrize("affine,mod", [(False, True), (True, False), (True, True)])
+def test_ln_modulate_on_fp32_rows(cuda, rows, dim, affine, mod):
+    g = torch.Generator().manual_seed(12)
+    x = 2.0 * torch.randn(rows, dim, generator=g) + 0.5          # fp32 values no bf16 tensor holds
+    w = 1 + 0.1 * torch.randn(dim, generator=g) if affine else None
+    b = 0.1 * torch.randn(dim, generator=g) if affine else None
+    sc = 0.2 * torch.randn(dim, generator=g) if mod else None
+    sh = 0.2 * torch.randn(dim, generator=g) if mod else None
+    ref = R.layer_norm(x, w, b)
+    if mod:
+        ref = R.modulate(ref, sc, sh)
+    out = hip.ln_modulate(x.to(cuda), w, b, sc, sh)
+    assert out.dtype == torch.bfloat16 and out.shape == (rows, dim)
+    assert (out.float().cpu() - ref).abs().max().item() <= BF16_EPS * ref.abs().max().item() + 1e-3
+    # the fp32 rows matter: the same call on their bf16 rounding gives another result
+    assert not torch.equal(out, hip.ln_modulate(x.to(torch.bfloat16).to(cuda), w, b, sc, sh)) or rows * dim < 512
+    # strided rows (a column range of a wider fp32 buffer)
+    wide = torch.zeros(rows, dim + 64, device=cuda)
+    wide[:, 32:32 + dim] = x.to(cuda)
+    if (32 * 4) % 16 == 0:
+        assert torch.equal(hip.ln_modulate(wide[:, 32:32 + dim], w, b, sc, sh), out)
+    with pytest.raises(hip.Lx2vError):
+        hip.ln_modulate(x.to(cuda), w, b, sc, sh, quant=True)
+
+
+@pytest.mark.parametrize("gated", [True, False])
+def test_gate_residual_on_fp32_rows(cuda, gated):
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(37, 1536, generator=g)
+    y = _rand((37, 1536), 7)
+    gate = 0.3 * torch.randn(1536, generator=g) if gated else None
+    ref = x + (y.float() * gate if gated else y.float())
+    xd = x.to(cuda)
+    out = hip.gate_residual_(xd, y.to(cuda), gate)
+    assert out.data_ptr() == xd.data_ptr() and out.dtype == torch.float32
+    # fp32 arithmetic: product and sum (a fused multiply-add differs from the two roundings by at most one unit in the last place)
+    assert (out.cpu() - ref).abs().max().item() <= 2.0 ** -22 * ref.abs().max().item()
+    # per-token gate
+    rowsmod = hip.RowMod(gate if gated else torch.zeros(1536), _rand((37, 1536), 14, 0.2).to(cuda))
+    x2 = x.to(cuda)
+    hip.gate_residual_(x2, y.to(cuda), rowsmod)
+    ref2 = x + y.float() * ((gate if gated else torch.zeros(1536)) + rowsmod.rows.float().cpu())
+    assert (x2.cpu() - ref2).abs().max().item() <= 2.0 ** -21 * ref2.abs().max().item()
+    with pytest.raises(hip.Lx2vError):
+        hip.gate_residual_(xd, x.to(cuda), gate)   # y must be bf16
+
+
 GEMM_SHAPES = [
     (256, 256, 64), (1, 256, 64), (300, 512, 128), (257, 264, 192), (1000, 1536, 1536), (520, 64, 1536),
     (512, 3072, 5120), (777, 8960, 1536), (333, 1536, 8960),

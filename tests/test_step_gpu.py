@@ -104,6 +104,29 @@ def test_denoise_loop_against_reference_trajectory(cuda, name):
     assert report[False][0] <= 5e-2 and report[False][1] >= 0.999
 
 
+def test_denoise_loop_with_fp32_residual_stream(cuda):
+    """The whole loop with `sensitive_layer_dtype: "fp32"` (x in fp32 between the Linears, through all
+    blocks and into the head): closer to the reference's fp32 trajectory than the bf16 stream."""
+    name = "step_small_d512"
+    rec, meta, model = step_case(name)
+    inputs = {"text_encoder_output": {"context": torch.from_numpy(rec["context"]).to(cuda), "context_null": torch.from_numpy(rec["context_null"]).to(cuda)}}
+    final = torch.from_numpy(rec[f"latents_{meta['steps']}"])
+    errs = {}
+    for mode in ("fp32", None):
+        m, sch = _model(meta, model, cuda, keep_latents_dtype_in_scheduler=True, sensitive_layer_dtype=mode)
+        assert m.transformer_infer.fp32_residual == (mode == "fp32")
+        sch.prepare(meta["seed"], meta["latent_shape"], latents=torch.from_numpy(rec["latents0"]))
+        for i in range(meta["steps"]):
+            sch.step_pre(i)
+            m.infer(inputs)
+            assert cos(sch.noise_pred, torch.from_numpy(rec[f"noise_pred_{i}"])) >= 0.999, (mode, i)
+            sch.step_post()
+        errs[mode] = (rel_err(sch.latents, final), cos(sch.latents, final))
+    print(f"\n{name}: final-latent max-rel-err / cosine, fp32 residual stream {errs['fp32'][0]:.3e} / {errs['fp32'][1]:.6f}; bf16 stream {errs[None][0]:.3e} / {errs[None][1]:.6f}")
+    assert errs["fp32"][0] <= 3e-2 and errs["fp32"][1] >= 0.9995
+    assert errs["fp32"][0] <= errs[None][0] * 1.05
+
+
 def test_scheduler_on_reference_noise_is_tight(cuda):
     """UniPC alone, fed the reference's own noise predictions: only fp32 rounding separates them."""
     rec, meta, model = step_case("step_tiny_d256")
