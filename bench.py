@@ -172,6 +172,65 @@ class AttnTimer:
         return sum(a.elapsed_time(b) for a, b in self.events)
 
 
+class KernelClassTimer:
+    """Event-timed wrappers around the binding's entry points (Linears, norms, every attention call):
+    where a step's time goes and what the GEMMs / norms achieve, measured inside this run (events on
+    the launch stream; a busy stream makes the span of a call its kernels' duration)."""
+
+    HBM_PEAK_GBS = 8000.0
+
+    def __init__(self):
+        from lightx2v_amd import hip
+
+        self.hip, self.enabled, self.rec, self._orig = hip, False, {}, {}
+        self._wrap("gemm", "linear_bf16", lambda a, w, *r, **kw: 2.0 * a.shape[0] * w.shape[0] * w.shape[1])
+        self._wrap("gemm_fp8", "linear_fp8", lambda a8, a_s, w8, *r, **kw: 2.0 * a8.shape[0] * w8.shape[0] * w8.shape[1])
+        self._wrap("ln_modulate", "norm", lambda x, *r, **kw: float(x.shape[0] * x.shape[1] * (x.element_size() + (1 if kw.get("quant") else 2))))
+        self._wrap("rmsnorm_rope", "norm", lambda x, *r, **kw: 4.0 * x.shape[0] * x.shape[1])
+        self._wrap("attn_fwd", "attention", lambda q, k, *r, **kw: 4.0 * q.shape[0] * k.shape[0] * q.shape[1] * q.shape[2])
+        self._wrap("attn_fwd_fp8", "attention", lambda q, k, *r, **kw: 4.0 * q.shape[0] * k.shape[0] * q.shape[1] * q.shape[2])
+
+    def _wrap(self, name, cls, work):
+        inner = getattr(self.hip, name)
+        self._orig[name] = inner
+        slot = self.rec.setdefault(cls, {"events": [], "work": 0.0, "calls": 0})
+
+        def timed(*a, **kw):
+            if not self.enabled:
+                return inner(*a, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream())
+            out = inner(*a, **kw)
+            e1.record(torch.cuda.current_stream())
+            slot["events"].append((e0, e1))
+            slot["work"] += work(*a, **kw)
+            slot["calls"] += 1
+            return out
+
+        setattr(self.hip, name, timed)
+
+    def summary(self, steps, step_ms, self_attn_ms_per_step):
+        """Per step: ms by kernel class (self-attention split out of `attention` by the caller's own timer),
+        GEMM TFLOP/s and norm GB/s over the timed steps."""
+        ms = {c: sum(a.elapsed_time(b) for a, b in r["events"]) / steps for c, r in self.rec.items()}
+        lin_ms = ms.get("linear_bf16", 0.0) + ms.get("linear_fp8", 0.0)
+        comp = {"self_attention": self_attn_ms_per_step, "cross_attention": max(0.0, ms.get("attention", 0.0) - self_attn_ms_per_step),
+                "linears": lin_ms, "norms": ms.get("norm", 0.0)}
+        comp["everything_else"] = max(0.0, step_ms - sum(comp.values()))
+        out = {"composition_ms_per_step": {k: round(v, 2) for k, v in comp.items()}}
+        for cls, peak, key in (("linear_bf16", MFMA_BF16_PEAK_TFLOPS, "linears_bf16"), ("linear_fp8", MFMA_FP8_PEAK_TFLOPS, "linears_fp8")):
+            r = self.rec[cls]
+            if r["calls"]:
+                t = r["work"] / (ms[cls] * steps * 1e-3) / 1e12
+                out[key] = {"achieved_tflops": t, "frac_of_mfma_peak": t / peak, "calls_timed": r["calls"], "ms_per_step": ms[cls]}
+        r = self.rec["norm"]
+        if r["calls"]:
+            g = r["work"] / (ms["norm"] * steps * 1e-3) / 1e9
+            out["norms"] = {"achieved_gbs": g, "frac_of_hbm_peak": g / self.HBM_PEAK_GBS, "calls_timed": r["calls"], "ms_per_step": ms["norm"],
+                            "bytes": "rows x dim x (bytes in + bytes out) per call"}
+        return out
+
+
 def cpu_model_name():
     try:
         for line in open("/proc/cpuinfo"):
@@ -309,6 +368,7 @@ def run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu):
     latents0 = torch.randn(1, C, *grid, generator=g2, device=dev, dtype=torch.float32).to(torch.bfloat16)
     sch.prepare(0, (C, *grid), image_encoder_output=inputs["image_encoder_output"], latents=latents0)
     timers = [AttnTimer(W.double_blocks[i].self_attention) for i in range(layers)]
+    classes = None if args.no_breakdown else KernelClassTimer()
     step_no = [0]
 
     def step():
@@ -331,6 +391,8 @@ def run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu):
         step()
     for t in timers:
         t.enabled = True
+    if classes is not None:
+        classes.enabled = True
     if world > 1 or args.sp1:
         ulysses.COMM_TIMER.enable()
     fence()
@@ -353,7 +415,9 @@ def run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu):
     Sj = S + HY_TEXT_LEN
     step_flops = (4.0 * Sj * Sj * D + 2.0 * Sj * D * (4 * D + 2 * F)) * layers
     frames = {31: 121, 21: 81}[grid[0]]
+    extra = {} if classes is None else classes.summary(args.steps, s_per_step * 1e3, sum(t.total_ms() for t in timers) / args.steps)
     return {
+        **extra,
         "metric": f"s/denoise-step {args.model} {args.res}{frames}f" + arithmetic_label(args)[1],
         "value": s_per_step, "unit": "s/denoise-step", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": s_per_step * 1e3, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
@@ -389,6 +453,7 @@ def main():
     ap.add_argument("--residual", default="bf16", choices=["bf16", "fp32"],
                     help="storage of the residual stream between the Linears: bf16 (the headline configuration) or fp32 (the reference's SENSITIVE_LAYER_DTYPE=FP32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-breakdown", action="store_true", help="do not time the Linears / norms / attention calls by class (events around each call)")
     ap.add_argument("--sp1", action="store_true",
                     help="one GPU only: run the sequence-parallel code path on an RCCL group of ONE rank (pack kernel, chunked attention, "
                          "asynchronous all-to-alls that move the rank's own data, segmented output projection, final all_gather); "
@@ -497,6 +562,7 @@ def main():
     if i2v_clip:
         inputs["image_encoder_output"]["clip_encoder_out"] = torch.randn(CLIP_TOKENS, CLIP_DIM, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
     timers = [AttnTimer(m.transformer_weights.blocks[i].compute_phases[0].self_attn_1) for m in experts for i in range(layers)]
+    classes = None if args.no_breakdown else KernelClassTimer()
     picks = []
 
     dbg = os.environ.get("LX2V_BENCH_DEBUG") == "1"
@@ -528,6 +594,8 @@ def main():
         step()
     for t in timers:
         t.enabled = True
+    if classes is not None:
+        classes.enabled = True
     if world > 1 or args.sp1:
         ulysses.COMM_TIMER.enable()
     fence()
@@ -575,6 +643,8 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_source,
                          "launch_ms": attn_ms, "flops_per_launch": attn_flops, "launches_timed": n_launches},
         }
+        if classes is not None:
+            line.update(classes.summary(args.steps, s_per_step * 1e3, sum(t.total_ms() for t in timers) / args.steps))
         if world == 1 and not args.no_cpu_baseline:
             threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
             line["cpu_baseline"] = cpu_baseline(D, H, F, S, layers, threads)
