@@ -229,8 +229,12 @@ class WanTransformerInfer:
         """Head: LN(x) * (1 + e1) + e0, then Linear D -> out (transformer_infer.py:75-97).  `e` is the
         time embedding [1, D], or [S, D] when the timestep is a per-token vector (the reference's
         2-D branch then broadcasts to a per-token modulation)."""
+        if e.dim() == 3 and e.shape[0] == 1:
+            # the reference's "diffusion forcing" branch (transformer_infer.py:79-82): e [1, S, D] broadcasts to the
+            # same per-token modulation as a 2-D e [S, D] does in its first branch
+            e = e[0]
         if e.dim() != 2:
-            raise NotImplementedError("3-D head modulation (diffusion forcing) is outside the Wan t2v/i2v path")
+            raise NotImplementedError(f"head modulation from an embedding of shape {tuple(e.shape)}: [1, D], [S, D] and [1, S, D] are built")
         table = weights.head_modulation.tensor.float().reshape(2, -1)
         if e.shape[0] == 1:
             mod = table + e.float()

@@ -227,6 +227,22 @@ def test_per_token_timestep_forward_against_reference(cuda):
         assert c >= 0.9995 and err <= 3e-2
 
 
+def test_head_accepts_the_three_dimensional_per_token_embedding(cuda):
+    """`infer_non_blocks` with e [1, S, D] (the reference's diffusion-forcing branch, transformer_infer.py:79-82)
+    is the per-token modulation its 2-D branch forms from e [S, D]."""
+    rec, meta, model = per_token_case()
+    m, sch = _model(dict(meta, steps=4, shift=5.0, guide=5.0), model, cuda)
+    g = torch.Generator().manual_seed(3)
+    S, D = 3 * 4 * 6, meta["dim"]
+    x = torch.randn(S, D, generator=g).to(torch.bfloat16).to(cuda)
+    e = (0.1 * torch.randn(S, D, generator=g)).to(torch.bfloat16).to(cuda)
+    two = m.transformer_infer.infer_non_blocks(m.transformer_weights, x, e)
+    three = m.transformer_infer.infer_non_blocks(m.transformer_weights, x, e.unsqueeze(0))
+    assert torch.equal(two, three)
+    with pytest.raises(NotImplementedError):
+        m.transformer_infer.infer_non_blocks(m.transformer_weights, x, e.reshape(2, S // 2, D))
+
+
 def test_row_modulation_kernels(cuda):
     g = torch.Generator().manual_seed(8)
     rows, dim = 37, 256
