@@ -1,0 +1,68 @@
+"""Block-scaled fp8 self-attention at the 720p x 81-frame token count (75 600): the long-sequence
+instance of the one-wave-per-SIMD kernel, many rounds of one workgroup per CU with round alignment,
+q / k / v as strided views of one [S, 3*H*128] buffer.  A few hundred query rows are checked against
+the CPU emulation of the scheme and against the fp32 softmax (both exact per row); whole outputs are
+compared between launch variants."""
+import pytest
+import torch
+
+from lightx2v_amd import hip
+from oracle import attn_fp8_ref as A8
+from oracle import wan_block_ref as R
+from tests.util import cos
+
+pytestmark = pytest.mark.gpu
+
+S, H, D = 75600, 3, 128   # 296 workgroups of 256 rows per head: 888 workgroups = 3.5 rounds
+
+
+@pytest.fixture(scope="module")
+def case(cuda):
+    g = torch.Generator(device=cuda).manual_seed(177)
+    qkv = torch.randn(S, 3 * H * D, generator=g, device=cuda, dtype=torch.float32).to(torch.bfloat16)
+    q, k, v = (qkv[:, i * H * D:(i + 1) * H * D].unflatten(1, (H, D)) for i in range(3))
+    edge = [0, 1, 31, 32, 63, 64, 255, 256, 257, S - 1, S - 2, S - 80, S - 81, S - 256, S - 257, 295 * 256 - 1, 295 * 256]
+    rows = torch.tensor(sorted(set(edge + torch.randint(0, S, (160,), generator=torch.Generator().manual_seed(6)).tolist())))
+    qs, kc, vc = q[rows.to(cuda)].cpu(), k.cpu(), v.cpu()
+    emu = A8.attention_fp8(qs, kc, vc)
+    ref = R.sdpa(qs.float(), kc.float(), vc.float())
+    return q, k, v, rows, emu, ref
+
+
+def test_sampled_rows_match_the_emulation_and_the_fp32_softmax(case):
+    q, k, v, rows, emu, ref = case
+    assert hip.get_option("attn_fp8_kernel") == 4
+    out = hip.attn_fwd_fp8(q, k, v)
+    assert out.shape == (S, H * D) and bool(torch.isfinite(out).all())
+    got = out[rows.to(out.device)].float().cpu()
+    rel_rms = ((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    print(f"\nfp8 attention at S={S}: cos vs fp32 {cos(got, ref):.6f} (emulation vs fp32 {cos(emu, ref):.6f}), cos vs emulation {cos(got, emu):.6f}, rel rms {rel_rms:.4f}")
+    assert cos(got, ref) >= 0.998 and rel_rms <= 0.06
+    assert cos(got, emu) >= 0.999
+    per_row = torch.nn.functional.cosine_similarity(got, ref, dim=1)
+    assert per_row.min().item() >= 0.99, (rows[per_row.argmin()].item(), per_row.min().item())
+
+
+def test_round_alignment_changes_nothing_and_the_kernels_agree(case, options):
+    q, k, v, _, _, _ = case
+    options(attn_round_sync=1)
+    base = hip.attn_fwd_fp8(q, k, v)
+    assert torch.equal(hip.attn_fwd_fp8(q, k, v), base)       # run-to-run deterministic
+    options(attn_round_sync=0)
+    assert torch.equal(hip.attn_fwd_fp8(q, k, v), base)       # a locality hint, not arithmetic
+    options(attn_round_sync=1)
+    hip.set_option("attn_fp8_kernel", 8)
+    try:
+        other = hip.attn_fwd_fp8(q, k, v)
+    finally:
+        hip.set_option("attn_fp8_kernel", 4)
+    a, b = base.float(), other.float()
+    rel_rms = ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
+    assert cos(a.cpu(), b.cpu()) >= 0.9993 and rel_rms <= 0.04    # same operands, other per-row offsets under which P is rounded
+
+
+def test_static_entry_point_refuses_this_size(case):
+    q, k, v, _, _, _ = case
+    assert hip.attn_fp8_workspace_bytes(S, S, H) > hip.attn_fp8_static_bytes()
+    with pytest.raises(hip.Lx2vError):
+        hip.attn_fwd_fp8_static(q, k, v, torch.empty(S, H * D, dtype=torch.bfloat16, device=q.device))
