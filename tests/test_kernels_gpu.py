@@ -181,6 +181,42 @@ def test_gemm_schedules_agree_bitwise(cuda, M, N, K, epi, options):
         assert torch.equal(run(), ref), i
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(75600, 5120, 5120, "resid"), (20000, 13824, 5120, "gelu"), (75600, 5120, 13824, "none")])
+def test_gemm_many_tiles_per_workgroup(cuda, M, N, K, epi, options):
+    """The 14B / 720p Linear shapes: thousands of output tiles, so every workgroup of the persistent
+    kernel walks some twenty of them back to back (loads of the next tile in flight during an
+    epilogue, partial last row panel, a last round that a few workgroups take alone).  Bit for bit
+    against the one-barrier schedule, and sampled rows against the fp32 product on the CPU."""
+    g = torch.Generator(device=cuda).manual_seed(50)
+    a = torch.randn(M, K, generator=g, device=cuda, dtype=torch.float32).to(torch.bfloat16)
+    w = (0.05 * torch.randn(N, K, generator=g, device=cuda, dtype=torch.float32)).to(torch.bfloat16)
+    b = 0.1 * torch.randn(N, generator=g, device=cuda, dtype=torch.float32)
+    gate = torch.randn(N, generator=g, device=cuda, dtype=torch.float32)
+    resid = torch.randn(M, N, generator=g, device=cuda, dtype=torch.float32).to(torch.bfloat16) if epi == "resid" else None
+
+    def run():
+        if epi == "gelu":
+            return hip.gemm(a, w, b, epilogue=hip.EPI_GELU_TANH)
+        if epi == "resid":
+            return hip.gemm(a, w, b, epilogue=hip.EPI_RESIDUAL, resid=resid, gate=gate)   # a new output tensor; resid is read only
+        return hip.gemm(a, w, b)
+
+    options(gemm_kernel=1)
+    ref = run()
+    options(gemm_kernel=0)
+    out = run()
+    assert torch.equal(out, ref)
+    assert torch.equal(run(), ref)
+    rows = torch.tensor(sorted({0, 1, 255, 256, 257, M - 1, M - 2, (M // 256) * 256 - 1, (M // 256) * 256} | set(torch.randint(0, M, (40,), generator=torch.Generator().manual_seed(51)).tolist())))
+    want = a[rows.to(cuda)].float().cpu() @ w.float().cpu().t() + b.cpu()
+    if epi == "gelu":
+        want = torch.nn.functional.gelu(want, approximate="tanh")
+    if epi == "resid":
+        want = resid[rows.to(cuda)].float().cpu() + want.to(torch.bfloat16).float() * gate.cpu()
+    got = out[rows.to(cuda)].float().cpu()
+    assert (got - want).abs().max().item() <= 2 * BF16_EPS * want.abs().max().item()
+
+
 def test_gemm_mfma_operand_orientation_identity(cuda):
     """A = I against an ASYMMETRIC W catches a transposed accumulator write-back."""
     n = 256
