@@ -218,7 +218,7 @@ class KernelClassTimer:
                 "linears": lin_ms, "norms": ms.get("norm", 0.0)}
         comp["everything_else"] = max(0.0, step_ms - sum(comp.values()))
         out = {"composition_ms_per_step": {k: round(v, 2) for k, v in comp.items()}}
-        for cls, peak, key in (("linear_bf16", MFMA_BF16_PEAK_TFLOPS, "linears_bf16"), ("linear_fp8", MFMA_FP8_PEAK_TFLOPS, "linears_fp8")):
+        for cls, peak, key in (("linear_bf16", MFMA_BF16_PEAK_TFLOPS, "linears_bf16"), ("linear_fp8", MFMA_FP8_PEAK_TFLOPS, "linears_w8a8")):
             r = self.rec[cls]
             if r["calls"]:
                 t = r["work"] / (ms[cls] * steps * 1e-3) / 1e12
@@ -284,9 +284,9 @@ def arithmetic_label(args):
         return d + " + fp32 residual stream", (suffix[:-1] + ", fp32 residual stream)") if suffix else " (fp32 residual stream)"
     if args.linear == "bf16" and args.attn == "bf16":
         return "bf16", ""
-    lin = "bf16 Linears" if args.linear == "bf16" else "fp8 Linears (W8A8 e4m3)"
+    lin = {"bf16": "bf16 Linears", "fp8": "fp8 Linears (W8A8 e4m3)", "int8": "int8 Linears (W8A8)"}[args.linear]
     att = "bf16 attention" if args.attn == "bf16" else "fp8 attention (block-scaled e4m3)"
-    return f"{lin} + {att}", " (" + ", ".join(x for x in ("fp8 Linears" if args.linear == "fp8" else "", "fp8 attention" if args.attn == "fp8" else "") if x) + ")"
+    return f"{lin} + {att}", " (" + ", ".join(x for x in (f"{args.linear} Linears" if args.linear != "bf16" else "", "fp8 attention" if args.attn == "fp8" else "") if x) + ")"
 
 
 def run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu):
@@ -312,7 +312,7 @@ def run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu):
         _, _, seq_group, _ = ulysses.make_groups(1, seq_p)
     C, TEXT_DIM, TXT_TOKENS, BYT5_TOKENS, VIS_TOKENS = 32, 3584, 1000, 256, 729
     cfg = {"mm_double_blocks_depth": layers, "heads_num": H, "hidden_size": D, "task": "t2v", "patch_size": (1, 1, 1), "out_channels": C,
-           "dit_quant_scheme": "hip-bf16" if args.linear == "bf16" else "hip-fp8",
+           "dit_quant_scheme": {"bf16": "hip-bf16", "fp8": "hip-fp8", "int8": "hip-int8"}[args.linear],
            "attn_type": "hip_flash_attn" if args.attn == "bf16" else "hip_fp8_attn",
            "seq_parallel": seq_p > 1 or args.sp1, "seq_p_group": seq_group, "parallel": {"seq_p_size": seq_p, "seq_p_attn_type": "hip_ulysses"},
            "enable_cfg": False, "sample_guide_scale": -1.0, "sample_shift": 5.0, "infer_steps": 4, "denoising_step_list": [1000, 750, 500, 250],
@@ -446,8 +446,8 @@ def main():
     ap.add_argument("--res", default=os.environ.get("LX2V_BENCH_RES", "720p"), choices=sorted(GRIDS))
     ap.add_argument("--layout", default=None, help="cfg_p x seq_p, e.g. 2x4 (default: 1x1, 2x1, 2x2, 2x4 for 1/2/4/8 GPUs)")
     ap.add_argument("--layers", type=int, default=None, help="override the layer count (debug only; the JSON line then says so)")
-    ap.add_argument("--linear", default="bf16", choices=["bf16", "fp8"],
-                    help="arithmetic of the blocks' Linears: bf16 (the headline configuration) or W8A8 e4m3 (the reference's fp8 schemes)")
+    ap.add_argument("--linear", default="bf16", choices=["bf16", "fp8", "int8"],
+                    help="arithmetic of the blocks' Linears: bf16 (the headline configuration), W8A8 e4m3 (the reference's fp8 schemes) or W8A8 int8 (its int8 schemes)")
     ap.add_argument("--attn", default="bf16", choices=["bf16", "fp8"],
                     help="self-attention arithmetic: bf16 (the headline configuration) or block-scaled e4m3 on the fp8 MFMA (where the reference would run a quantised backend)")
     ap.add_argument("--residual", default="bf16", choices=["bf16", "fp32"],
@@ -528,7 +528,7 @@ def main():
     cfg = {"num_layers": layers, "num_heads": H, "dim": D, "ffn_dim": F, "task": "t2v", "model_cls": "wan2.1",
            "in_dim": LATENT_CHANNELS, "out_dim": LATENT_CHANNELS, "freq_dim": 256, "infer_steps": 50, "sample_shift": 5.0,
            "sample_guide_scale": GUIDE_SCALE, "enable_cfg": True, "run_device": "cuda",
-           "dit_quant_scheme": "hip-bf16" if args.linear == "bf16" else "hip-fp8",
+           "dit_quant_scheme": {"bf16": "hip-bf16", "fp8": "hip-fp8", "int8": "hip-int8"}[args.linear],
            "self_attn_1_type": "hip_flash_attn" if args.attn == "bf16" else "hip_fp8_attn",
            "sensitive_layer_dtype": "fp32" if args.residual == "fp32" else "bf16",
            "cfg_parallel": cfg_p > 1, "cfg_p_group": cfg_group,

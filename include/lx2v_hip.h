@@ -318,6 +318,28 @@ int lx2v_gemm_fp8(const uint8_t* A, int64_t lda, const float* a_scale, const uin
                   int64_t N, int64_t K, int epilogue, const uint16_t* resid, int64_t ldr,
                   const float* gate, void* stream);
 
+/* ==== int8 W8A8 Linear on the int8 MFMA ===================================================== */
+
+/* ---- row-wise symmetric int8 quantisation (round half to even, saturating to [-128, 127]) ------
+ * weight_mode 0, activations per token: scale[r] = max|x[r,:]| / 127 ; out = rint(x * (127 / max|x[r,:]|)).
+ *   Replaces act_quant_int8_perchannel_sym_vllm (vllm ops.scaled_int8_quant(x, scale=None, azp=None,
+ *   symmetric=True), dynamic per-token)  lightx2v/common/ops/mm/mm_weight.py:503-505.
+ * weight_mode 1, weights per output channel: scale[r] = max(max|x[r,:]|, 1e-5) / 127 ; out = rint(x / scale[r]).
+ *   Replaces IntegerQuantizer(8, True, "per_channel").real_quant_tensor as load_int8_perchannel_sym uses it
+ *   lightx2v/common/ops/mm/mm_weight.py:322-330, lightx2v/utils/quant_utils.py:39-49,85-92,111-113. */
+int lx2v_quant_int8_rowwise(const uint16_t* x, int64_t ldx, int8_t* out, int64_t ldo, float* scale,
+                            int64_t rows, int dim, int weight_mode, void* stream);
+
+/* ---- C[M,N] = epilogue((A8 @ W8^T) * a_scale[m] * w_scale[n] + bias), bf16 out ---------------
+ * lx2v_gemm_fp8 with int8 operands: the products are accumulated exactly in int32, converted to fp32
+ * once, then scaled.  K % 128 == 0, K <= 131072, N % 8 == 0, row strides % 16.
+ * Replaces MMWeightWint8channelAint8channeldynamicVllm.apply ("int8-vllm": cutlass_scaled_mm) and its
+ * sgl / q8f / torchao siblings  lightx2v/common/ops/mm/mm_weight.py:607-641,836-866,931-990. */
+int lx2v_gemm_int8(const int8_t* A, int64_t lda, const float* a_scale, const int8_t* W, int64_t ldw,
+                   const float* w_scale, const float* bias, uint16_t* C, int64_t ldc, int64_t M,
+                   int64_t N, int64_t K, int epilogue, const uint16_t* resid, int64_t ldr,
+                   const float* gate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,7 @@ void lx2v_set_error(const char* fmt, ...) {
 
 extern "C" const char* lx2v_last_error(void) { return g_err; }
 
-extern "C" int lx2v_abi_version(void) { return 3; }
+extern "C" int lx2v_abi_version(void) { return 4; }
 
 namespace {
 

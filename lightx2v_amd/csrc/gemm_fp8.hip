@@ -7,6 +7,11 @@
 // one v_mfma_scale_f32_16x16x128_f8f6f4 (unit scales) covers its whole depth: half as many MFMAs
 // per byte staged, each at twice the bf16 rate.  A lane's operand is 32 consecutive K bytes
 // (k-block lane/16), i.e. two adjacent 16-byte chunks of the swizzled row.
+//
+// The one-barrier kernel also serves int8 W8A8 (lx2v_gemm_int8): same tiles, same LDS image, the
+// lane's 32 K bytes go through two v_mfma_i32_16x16x64_i8 (first and second 16 bytes; both operands
+// use the same split, so every K index meets its partner), accumulation is exact in int32 and the
+// accumulators are converted to fp32 in front of the shared epilogue.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -108,7 +113,9 @@ LX2V_DEVICE void gemm_fp8_epilogue(const GemmParams& p, f32x4 (&acc)[4][8], char
   }
 }
 
-template <int EPI>
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+template <int EPI, bool INT8 = false>
 __global__ __launch_bounds__(NTHREADS) void gemm_fp8_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];  // [stage][A|W][32 KiB]
 
@@ -198,11 +205,29 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fp8_kernel(const GemmParams p) 
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int m4 = 0; m4 < 4; ++m4)
-          acc[nt][mh * 4 + m4] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[nt], af[m4], acc[nt][mh * 4 + m4], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        for (int m4 = 0; m4 < 4; ++m4) {
+          if constexpr (INT8) {
+            // int32 accumulators in the same registers (bit pattern kept in the f32x4 slots until the loop ends)
+            i32x4 c = __builtin_bit_cast(i32x4, acc[nt][mh * 4 + m4]);
+            c = __builtin_amdgcn_mfma_i32_16x16x64_i8(i32x4{wf[nt][0], wf[nt][1], wf[nt][2], wf[nt][3]}, i32x4{af[m4][0], af[m4][1], af[m4][2], af[m4][3]}, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_i32_16x16x64_i8(i32x4{wf[nt][4], wf[nt][5], wf[nt][6], wf[nt][7]}, i32x4{af[m4][4], af[m4][5], af[m4][6], af[m4][7]}, c, 0, 0, 0);
+            acc[nt][mh * 4 + m4] = __builtin_bit_cast(f32x4, c);
+          } else {
+            acc[nt][mh * 4 + m4] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[nt], af[m4], acc[nt][mh * 4 + m4], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+          }
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+  }
+  if constexpr (INT8) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) {
+        const i32x4 c = __builtin_bit_cast(i32x4, acc[nt][mt]);
+        acc[nt][mt] = f32x4{(float)c[0], (float)c[1], (float)c[2], (float)c[3]};
+      }
   }
 
   gemm_fp8_epilogue<EPI>(p, acc, lds, m0, n0, wid, wm, wn, lane);
@@ -392,9 +417,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fp8_pp_kernel(const GemmParams 
 
 }  // namespace
 
-extern "C" int lx2v_gemm_fp8(const uint8_t* A, int64_t lda, const float* a_scale, const uint8_t* W, int64_t ldw, const float* w_scale,
-                             const float* bias, uint16_t* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
-                             const uint16_t* resid, int64_t ldr, const float* gate, void* stream) {
+static int gemm_w8a8(bool int8, const uint8_t* A, int64_t lda, const float* a_scale, const uint8_t* W, int64_t ldw, const float* w_scale,
+                     const float* bias, uint16_t* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
+                     const uint16_t* resid, int64_t ldr, const float* gate, void* stream) {
   LX2V_REQUIRE(M == 0 || (A && W && C && a_scale && w_scale), LX2V_EINVAL, "gemm_fp8: null tensor");
   LX2V_REQUIRE(M >= 0 && N > 0 && K > 0, LX2V_EINVAL, "gemm_fp8: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
   LX2V_REQUIRE(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), LX2V_EUNSUP, "gemm_fp8: dimensions must fit in 31 bits");
@@ -424,6 +449,16 @@ extern "C" int lx2v_gemm_fp8(const uint8_t* A, int64_t lda, const float* a_scale
   // The one-barrier-per-K-tile schedule is the default here: at 14B shapes it measured 2.0-2.24 PFLOP/s
   // against 1.87-2.11 for the ping-pong schedule (which wins by 10 % on the bf16 GEMM).
   // Option gemm_kernel = 2 selects the latter (A/B switch).
+  if (int8) {
+    LX2V_REQUIRE(K <= 131072, LX2V_EUNSUP, "gemm_int8: K=%lld: the int32 accumulators hold 127 * 127 * K up to K = 131072", (long long)K);
+    switch (epilogue) {
+      case LX2V_EPI_NONE: hipLaunchKernelGGL((gemm_fp8_kernel<LX2V_EPI_NONE, true>), grid, block, 0, st, p); break;
+      case LX2V_EPI_GELU_TANH: hipLaunchKernelGGL((gemm_fp8_kernel<LX2V_EPI_GELU_TANH, true>), grid, block, 0, st, p); break;
+      default: hipLaunchKernelGGL((gemm_fp8_kernel<LX2V_EPI_RESIDUAL, true>), grid, block, 0, st, p); break;
+    }
+    LX2V_CHECK_LAUNCH("gemm_int8");
+    return LX2V_OK;
+  }
   const bool simple = lx2v_options().gemm_kernel != 2;
   if (simple || K < 2 * BK) {
     switch (epilogue) {
@@ -440,4 +475,17 @@ extern "C" int lx2v_gemm_fp8(const uint8_t* A, int64_t lda, const float* a_scale
   }
   LX2V_CHECK_LAUNCH("gemm_fp8");
   return LX2V_OK;
+}
+
+extern "C" int lx2v_gemm_fp8(const uint8_t* A, int64_t lda, const float* a_scale, const uint8_t* W, int64_t ldw, const float* w_scale,
+                             const float* bias, uint16_t* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
+                             const uint16_t* resid, int64_t ldr, const float* gate, void* stream) {
+  return gemm_w8a8(false, A, lda, a_scale, W, ldw, w_scale, bias, C, ldc, M, N, K, epilogue, resid, ldr, gate, stream);
+}
+
+extern "C" int lx2v_gemm_int8(const int8_t* A, int64_t lda, const float* a_scale, const int8_t* W, int64_t ldw, const float* w_scale,
+                              const float* bias, uint16_t* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
+                              const uint16_t* resid, int64_t ldr, const float* gate, void* stream) {
+  return gemm_w8a8(true, reinterpret_cast<const uint8_t*>(A), lda, a_scale, reinterpret_cast<const uint8_t*>(W), ldw, w_scale, bias, C, ldc, M, N, K, epilogue,
+                   resid, ldr, gate, stream);
 }

@@ -200,6 +200,44 @@ __global__ __launch_bounds__(256) void quant_fp8_rowwise_kernel(const uint16_t* 
   }
 }
 
+// Row-wise symmetric int8 quantisation, round half to even, saturating to [-128, 127].  Same row handling as the fp8 kernel above.
+//   weight_mode 0 (activations; the dynamic per-token form of vLLM's scaled_int8_quant): scale[r] = max|x[r,:]| / 127,
+//     out = rint(x * (127 / max|x[r,:]|)); a row of zeros gets scale 0 and zeros.
+//   weight_mode 1 (weights; the reference's IntegerQuantizer(8, True, "per_channel"), lightx2v/utils/quant_utils.py:43-49,111-113):
+//     scale[r] = max(max|x[r,:]|, 1e-5) / 127, out = rint(x / scale[r]).
+__global__ __launch_bounds__(256) void quant_int8_rowwise_kernel(const uint16_t* __restrict__ x, int64_t ldx, int8_t* __restrict__ out, int64_t ldo,
+                                                                 float* __restrict__ scale, int64_t rows, int dim, int lpr, int weight_mode) {
+  const int lane = threadIdx.x & 63;
+  const int l = lane & (lpr - 1);
+  const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / lpr) + lane / lpr;
+  if (row >= rows) return;
+  const uint16_t* xr = x + row * ldx;
+  const int nchunks = dim >> 3;
+  float amax = 0.f;
+  for (int ch = l; ch < nchunks; ch += lpr) {
+    float f[8];
+    unpack8(*reinterpret_cast<const u32x4*>(xr + (int64_t)ch * 8), f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(f[i]));
+  }
+  for (int off = lpr >> 1; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+  const float inv = amax > 0.f ? __fdiv_rn(127.0f, amax) : 0.f;
+  const float sc = weight_mode ? __fdiv_rn(fmaxf(amax, 1e-5f), 127.0f) : __fdiv_rn(amax, 127.0f);
+  if (l == 0) scale[row] = sc;
+  int8_t* orow = out + row * ldo;
+  for (int ch = l; ch < nchunks; ch += lpr) {
+    float f[8];
+    unpack8(*reinterpret_cast<const u32x4*>(xr + (int64_t)ch * 8), f);
+    uint32_t w[2] = {0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float r = fminf(fmaxf(rintf(weight_mode ? __fdiv_rn(f[i], sc) : __fmul_rn(f[i], inv)), -128.0f), 127.0f);
+      w[i >> 2] |= ((uint32_t)(int)r & 0xffu) << (8 * (i & 3));
+    }
+    *reinterpret_cast<u32x2*>(orow + (int64_t)ch * 8) = u32x2{w[0], w[1]};
+  }
+}
+
 // out[r, :] = bf16(e4m3(q[r, :]) * bf16(scale[r])): the value a bf16 multiply of the widened
 // byte by the bf16-rounded scale gives (one rounding: the fp32 product of two bf16 values is exact).
 __global__ __launch_bounds__(256) void dequant_fp8_rowwise_kernel(const uint8_t* __restrict__ q, int64_t ldq, const float* __restrict__ scale,
@@ -348,6 +386,22 @@ extern "C" int lx2v_quant_fp8_rowwise(const uint16_t* x, int64_t ldx, uint8_t* o
   hipLaunchKernelGGL(quant_fp8_rowwise_kernel, dim3((unsigned)((rows + rows_per_block - 1) / rows_per_block)), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo,
                      scale, rows, dim, lpr);
   LX2V_CHECK_LAUNCH("quant_fp8");
+  return LX2V_OK;
+}
+
+extern "C" int lx2v_quant_int8_rowwise(const uint16_t* x, int64_t ldx, int8_t* out, int64_t ldo, float* scale, int64_t rows, int dim, int weight_mode, void* stream) {
+  LX2V_REQUIRE(rows == 0 || (x && out && scale), LX2V_EINVAL, "quant_int8: null tensor");
+  LX2V_REQUIRE(rows >= 0 && dim > 0 && dim % 8 == 0, LX2V_EINVAL, "quant_int8: dim=%d must be a positive multiple of 8", dim);
+  LX2V_REQUIRE(ldx % 8 == 0 && ldo % 8 == 0 && ldx >= dim && ldo >= dim, LX2V_EINVAL, "quant_int8: row strides must be multiples of 8 and >= dim");
+  LX2V_REQUIRE(lx2v_aligned16(x) && (reinterpret_cast<uintptr_t>(out) & 7u) == 0, LX2V_EINVAL, "quant_int8: x must be 16-byte, out 8-byte aligned");
+  if (rows == 0) return LX2V_OK;
+  const int nchunks = dim >> 3;
+  int lpr = 64;
+  if (nchunks <= 32 && (nchunks & (nchunks - 1)) == 0) lpr = nchunks;  // short rows share a wave
+  const int64_t rows_per_block = 4 * (64 / lpr);
+  hipLaunchKernelGGL(quant_int8_rowwise_kernel, dim3((unsigned)((rows + rows_per_block - 1) / rows_per_block)), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo,
+                     scale, rows, dim, lpr, weight_mode != 0);
+  LX2V_CHECK_LAUNCH("quant_int8");
   return LX2V_OK;
 }
 

@@ -15,7 +15,7 @@ from typing import Optional
 import torch
 
 _LIB_NAME = "liblx2v_hip.so"
-ABI_VERSION = 3  # include/lx2v_hip.h: lx2v_abi_version()
+ABI_VERSION = 4  # include/lx2v_hip.h: lx2v_abi_version()
 _lib: Optional[ctypes.CDLL] = None
 
 EPI_NONE, EPI_GELU_TANH, EPI_RESIDUAL = 0, 1, 2
@@ -55,6 +55,8 @@ _SIGNATURES = {
     "lx2v_quant_fp8_rowwise": [_P, _I64, _P, _I64, _P, _I64, _I, _P],
     "lx2v_dequant_fp8_rowwise": [_P, _I64, _P, _P, _I64, _I64, _I, _P],
     "lx2v_gemm_fp8": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _P, _I64, _P, _P],
+    "lx2v_quant_int8_rowwise": [_P, _I64, _P, _I64, _P, _I64, _I, _I, _P],
+    "lx2v_gemm_int8": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _P, _I64, _P, _P],
 }
 EXPORTS = tuple(_SIGNATURES) + ("lx2v_abi_version", "lx2v_last_error")
 
@@ -594,6 +596,19 @@ def quant_fp8_rowwise(x: torch.Tensor):
     return q, scale
 
 
+def quant_int8_rowwise(x: torch.Tensor, weight_mode: bool = False):
+    """bf16 [rows, dim] -> (int8 [rows, dim], fp32 scale [rows]); x ~= q * scale.  `weight_mode`: the
+    reference's per-channel weight quantiser (division by the scale, scale floor 1e-5 / 127) instead of
+    the per-token activation form (multiplication by 127 / max)."""
+    _need_bf16_cuda("quant_int8.x", x)
+    rows, dim = x.shape
+    q = torch.empty((rows, dim), dtype=torch.int8, device=x.device)
+    scale = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    _check(load().lx2v_quant_int8_rowwise(x.data_ptr(), x.stride(0), q.data_ptr(), q.stride(0), scale.data_ptr(), rows, dim, int(bool(weight_mode)), _stream()),
+           "lx2v_quant_int8_rowwise")
+    return q, scale
+
+
 def dequant_fp8_rowwise(q: torch.Tensor, scale: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """e4m3 [rows, dim] and fp32 scale [rows] -> bf16 [rows, dim] = q.to(bf16) * scale.to(bf16)."""
     if not q.is_cuda or q.dtype != torch.float8_e4m3fn or q.dim() != 2 or q.stride(1) != 1:
@@ -607,12 +622,18 @@ def dequant_fp8_rowwise(q: torch.Tensor, scale: torch.Tensor, out: Optional[torc
     return out
 
 
+def gemm_int8(a8: torch.Tensor, a_scale: torch.Tensor, w8: torch.Tensor, w_scale: torch.Tensor, bias=None, epilogue: int = EPI_NONE,
+              resid: Optional[torch.Tensor] = None, gate=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(a8 [M,K] int8) @ (w8 [N,K] int8)^T, exact in int32, scaled per row / per output channel -> bf16 [M,N]."""
+    return gemm_fp8(a8, a_scale, w8, w_scale, bias, epilogue, resid, gate, out, _dtype=torch.int8)
+
+
 def gemm_fp8(a8: torch.Tensor, a_scale: torch.Tensor, w8: torch.Tensor, w_scale: torch.Tensor, bias=None, epilogue: int = EPI_NONE,
-             resid: Optional[torch.Tensor] = None, gate=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+             resid: Optional[torch.Tensor] = None, gate=None, out: Optional[torch.Tensor] = None, _dtype=torch.float8_e4m3fn) -> torch.Tensor:
     """(a8 [M,K] e4m3) @ (w8 [N,K] e4m3)^T scaled per row / per output channel -> bf16 [M,N]."""
     for n, t in (("a8", a8), ("w8", w8)):
-        if not t.is_cuda or t.dtype != torch.float8_e4m3fn or t.stride(-1) != 1:
-            raise Lx2vError(f"gemm_fp8: {n} must be a GPU float8_e4m3fn tensor with a contiguous inner dimension")
+        if not t.is_cuda or t.dtype != _dtype or t.stride(-1) != 1:
+            raise Lx2vError(f"gemm_fp8: {n} must be a GPU {_dtype} tensor with a contiguous inner dimension")
     M, K = a8.shape
     N = w8.shape[0]
     if w8.shape[1] != K:
@@ -629,7 +650,8 @@ def gemm_fp8(a8: torch.Tensor, a_scale: torch.Tensor, w8: torch.Tensor, w_scale:
         _need_out("gemm_fp8.resid", resid, (M, N), a8)
     elif epilogue == EPI_RESIDUAL:
         raise Lx2vError("gemm_fp8: the residual epilogue needs `resid`")
-    st = load().lx2v_gemm_fp8(a8.data_ptr(), a8.stride(0), a_scale.data_ptr(), w8.data_ptr(), w8.stride(0), w_scale.data_ptr(), _ptr(bias),
-                              out.data_ptr(), out.stride(0), M, N, K, epilogue, _ptr(resid), 0 if resid is None else resid.stride(0), _ptr(gate), _stream())
-    _check(st, "lx2v_gemm_fp8")
+    entry = "lx2v_gemm_int8" if _dtype == torch.int8 else "lx2v_gemm_fp8"
+    st = getattr(load(), entry)(a8.data_ptr(), a8.stride(0), a_scale.data_ptr(), w8.data_ptr(), w8.stride(0), w_scale.data_ptr(), _ptr(bias),
+                                out.data_ptr(), out.stride(0), M, N, K, epilogue, _ptr(resid), 0 if resid is None else resid.stride(0), _ptr(gate), _stream())
+    _check(st, entry)
     return out

@@ -349,6 +349,40 @@ class HipFp8MMWeight(HipMMWeight):
         return self._run(input_tensor, hip.EPI_RESIDUAL, resid=resid, gate=gate)
 
 
+@MM_WEIGHT_REGISTER("hip-int8")
+class HipInt8MMWeight(HipFp8MMWeight):
+    """W8A8 in int8 on the int8 MFMA: per-output-channel symmetric weight scale, dynamic per-token
+    symmetric activation scale, exact int32 accumulation, bf16 output -- the semantics of the
+    reference's "int8-vllm" / "int8-sgl" / "int8-q8f" / "int8-torchao" schemes
+    (lightx2v/common/ops/mm/mm_weight.py:607-641,836-866,931-990).  Loads a pre-quantised checkpoint
+    (`<name>.weight` int8 + `<name>.weight_scale`, `load_quantized`) or, like `weight_auto_quant`
+    (:322-330), quantises a bf16 / fp32 weight at load time with the reference's per-channel formula."""
+
+    accepts_quantized = False  # the LayerNorm kernel's fused output is e4m3
+
+    def load(self, weight_dict):
+        w = weight_dict[self.weight_name]
+        b = weight_dict[self.bias_name] if self.bias_name is not None else None
+        self.bias = _device_ready(b, torch.float32)
+        if w.dtype == torch.int8:
+            self.weight_nk = w.contiguous()
+            self.weight_scale = weight_dict[self.weight_scale_name].to(torch.float32).reshape(-1).contiguous()
+        else:
+            if not w.is_cuda:
+                if not torch.cuda.is_available():
+                    raise RuntimeError("hip-int8: quantising a weight at load time runs on the GPU; no GPU is visible (no CPU fallback exists)")
+                w = w.cuda()
+            self.weight_nk, self.weight_scale = hip.quant_int8_rowwise(w.to(COMPUTE_DTYPE).contiguous(), weight_mode=True)
+
+    def load_state_dict(self, destination, block_index, adapter_block_index=None):
+        raise NotImplementedError("hip-int8: block-streamed (offload) loading is not built")
+
+    def _run(self, x, epilogue, resid=None, gate=None, out=None):
+        xq, xs = hip.quant_int8_rowwise(x)
+        return hip.gemm_int8(xq, xs, self.weight_nk, self.weight_scale, self.bias, epilogue=epilogue, resid=resid, gate=gate,
+                             out=resid if epilogue == hip.EPI_RESIDUAL else out)
+
+
 # ----------------------------------------------------------------------------------- norms
 def _all_take_quantized(consumers) -> bool:
     if consumers is None:

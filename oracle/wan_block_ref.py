@@ -369,6 +369,43 @@ def linear_fp8(x: torch.Tensor, w_q: torch.Tensor, w_scale: torch.Tensor, b: Opt
     return y if b is None else y + b
 
 
+def quant_int8_weight(w: torch.Tensor):
+    """The reference's per-output-channel int8 weight quantiser, `IntegerQuantizer(8, True, "per_channel")
+    .real_quant_tensor` as `load_int8_perchannel_sym` calls it (lightx2v/common/ops/mm/mm_weight.py:322-330;
+    lightx2v/utils/quant_utils.py:29-36 range, :39-49 scale = clamp(absmax, 1e-5) / 127, :111-113
+    q = clamp(round(w / scale), -128, 127)).  PINNED by that class itself (tests/golden/int8_weight_quant.npz,
+    oracle/gen_golden_int8.py).  Returns (q int8, scale fp32 [rows])."""
+    w = w.float()
+    absmax = torch.max(w.amax(dim=-1, keepdim=True).abs(), w.amin(dim=-1, keepdim=True).abs()).clamp(min=1e-5)
+    scale = absmax / 127.0
+    q = torch.clamp(torch.round(w / scale), -128, 127)
+    return q.to(torch.int8), scale.reshape(-1)
+
+
+def quant_int8_rowwise(x: torch.Tensor):
+    """Dynamic symmetric int8 quantisation with one scale per token, `act_quant_int8_perchannel_sym_vllm`
+    (mm_weight.py:503-505) = vllm `ops.scaled_int8_quant(x, scale=None, azp=None, symmetric=True)`.  vllm
+    0.9.2 is absent here and the reference holds no fixture for it: parity unpinned -- this is the
+    published kernel's arithmetic (csrc/quantization/compressed_tensors/int8_quant_kernels.cu,
+    dynamic_scaled_int8_quant_kernel): scale = absmax / 127, q = saturate(nearbyint(x * (127 / absmax))).
+    Returns (q int8, scale fp32 [rows])."""
+    x = x.float()
+    absmax = x.abs().amax(dim=1)
+    # a true fp32 division, as the kernel's `127.0f / absmax` (a Python scalar divided by a tensor is reciprocal-then-multiply in torch: two roundings)
+    inv = torch.where(absmax > 0, torch.full_like(absmax, 127.0) / absmax, torch.zeros_like(absmax))
+    q = torch.clamp(torch.round(x * inv[:, None]), -128, 127)
+    return q.to(torch.int8), absmax / 127.0
+
+
+def linear_int8(x: torch.Tensor, w_q: torch.Tensor, w_scale: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`int8-vllm` apply (mm_weight.py:623-640, cutlass_scaled_mm): quantise x per token, multiply
+    exactly in the integer domain, rescale by both scales, add the bias."""
+    x_q, x_scale = quant_int8_rowwise(x)
+    acc = (x_q.to(torch.int64) @ w_q.to(torch.int64).t()).to(torch.int32)   # exact
+    y = acc.float() * x_scale[:, None] * w_scale[None, :]
+    return y if b is None else y + b
+
+
 def dequant_fp8_rowwise(q: torch.Tensor, scale: torch.Tensor, dtype=torch.bfloat16) -> torch.Tensor:
     """`dequant_fp8_vllm` (lightx2v/utils/quant_utils.py:185-186): q.to(dtype) * scale.to(dtype), one
     scale per row."""

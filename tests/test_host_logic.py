@@ -59,7 +59,7 @@ def test_c_abi_exports_every_declared_symbol():
     lib = ctypes.CDLL(hip.lib_path())
     for name in declared:
         assert hasattr(lib, name), name
-    assert hip.load().lx2v_abi_version() == hip.ABI_VERSION == 3
+    assert hip.load().lx2v_abi_version() == hip.ABI_VERSION == 4
 
 
 def test_ops_refuse_cpu_tensors_loudly():

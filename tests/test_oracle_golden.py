@@ -73,3 +73,21 @@ def test_ulysses_model_matches_reference_gloo_run(world):
     s2h = R.seq2head_reference(list(q.chunk(world)))
     assert torch.equal(s2h[1], torch.from_numpy(rec["s2h_rank1"]))
     assert (torch.cat(outs, 0) - R.sdpa(q, k, v)).abs().max().item() < 1e-5
+
+
+def test_int8_weight_quantiser_restatement_matches_the_references_own():
+    """oracle.wan_block_ref.quant_int8_weight against the fixture the reference's IntegerQuantizer wrote."""
+    import numpy as np
+    import torch
+
+    from oracle import wan_block_ref as R
+    from tests.util import load_golden
+
+    rec = load_golden("int8_weight_quant")
+    w = torch.from_numpy(rec["w_bf16_bits"]).view(torch.bfloat16)
+    q, s = R.quant_int8_weight(w)
+    assert torch.equal(q, torch.from_numpy(rec["q"])) and torch.equal(s, torch.from_numpy(rec["scale"]))
+    assert int(q[3].abs().max()) == 0 and float(s[3]) == np.float32(1e-5) / np.float32(127.0)   # the all-zero channel sits on the scale floor
+    # the activation form: a row of zeros keeps scale 0; full range is used
+    xq, xs = R.quant_int8_rowwise(torch.cat([w.float(), torch.zeros(1, w.shape[1])]))
+    assert float(xs[-1]) == 0.0 and int(xq[-1].abs().max()) == 0 and int(xq.abs().max()) == 127
