@@ -86,7 +86,7 @@ def _finish():
 H10_CASE = {"grid": (3, 5, 7), "dim": 1280, "heads": 10, "ffn": 2560, "text_len": 77, "seed": 11}  # 5 heads per rank of 2: chunks of 3 + 2
 
 
-def _worker(rank, world, port, out_dir, fused, fp8_comm=False, case=None, rccl=False):
+def _worker(rank, world, port, out_dir, fused, fp8_comm=False, case=None, rccl=False, fp32_stream=False):
     dev = _init_rccl(port) if rccl else _init(rank, world, port)
     import lightx2v_amd as L
     from lightx2v_amd import ulysses
@@ -97,7 +97,8 @@ def _worker(rank, world, port, out_dir, fused, fp8_comm=False, case=None, rccl=F
     c = case_inputs(rec)
     _, seq_idx, seq_group, _ = ulysses.make_groups(1, world)
     cfg = {"num_layers": 1, "num_heads": c["heads"], "dim": c["dim"], "task": "t2v", "seq_parallel": True, "seq_p_group": seq_group,
-           "parallel": {"seq_p_size": world, "seq_p_attn_type": "hip_ulysses", "seq_p_fp8_comm": fp8_comm}, "fused_block": fused}
+           "parallel": {"seq_p_size": world, "seq_p_attn_type": "hip_ulysses", "seq_p_fp8_comm": fp8_comm}, "fused_block": fused,
+           "sensitive_layer_dtype": "fp32" if fp32_stream else "bf16"}
     W = L.WanTransformerWeights(cfg)
     wd = dict(c["w"]); wd.update(c["hw"])
     W.load(wd); W.to_cuda()
@@ -112,7 +113,8 @@ def _worker(rank, world, port, out_dir, fused, fp8_comm=False, case=None, rccl=F
     xl = x[seq_idx * S_loc:(seq_idx + 1) * S_loc].to(torch.bfloat16).to(dev).contiguous()
     pre = L.WanPreInferModuleOutput(embed=c["embed"].to(dev), grid_sizes=c["grid"], x=xl, embed0=c["embed0"].to(dev),
                                     context=c["context"].to(torch.bfloat16).to(dev))
-    out = inf.infer_block(W.blocks[0], pre.x, pre)
+    out = inf.infer_main_blocks(W.blocks, pre) if fp32_stream else inf.infer_block(W.blocks[0], pre.x, pre)
+    assert out.dtype == (torch.float32 if fp32_stream else torch.bfloat16)
     torch.cuda.synchronize()
     torch.save(out.float().cpu(), os.path.join(out_dir, f"o{rank}_{int(fused)}{'_fp8' if fp8_comm else ''}.pt"))
     _finish()
@@ -324,15 +326,15 @@ def test_hunyuan_model_infer_with_cfg_and_sequence_parallel_groups(cuda, tmp_pat
 
 
 # ---- the same paths over RCCL (one rank: the one-GPU box cannot hold two) ----
-@pytest.mark.parametrize("fused,fp8_comm", [(True, False), (False, False), (True, True)])
-def test_sequence_parallel_block_over_rccl_one_rank(cuda, tmp_path, fused, fp8_comm):
+@pytest.mark.parametrize("fused,fp8_comm,fp32_stream", [(True, False, False), (False, False, False), (True, True, False), (True, False, True)])
+def test_sequence_parallel_block_over_rccl_one_rank(cuda, tmp_path, fused, fp8_comm, fp32_stream):
     """The block with `seq_parallel` on a sequence group of one rank whose collectives are RCCL's:
     the head chunks (the one rank's 10 heads in chunks of 5 and 5), the asynchronous all-to-alls,
     their waits and the segmented output projection run against the production transport.  A group of one pads nothing, so the result is the unsharded block's."""
     from oracle import wan_block_ref as R
     from tests.util import case_inputs, cos
 
-    _spawn(_worker, lambda port: (1, port, str(tmp_path), fused, fp8_comm, H10_CASE, True), 1)
+    _spawn(_worker, lambda port: (1, port, str(tmp_path), fused, fp8_comm, H10_CASE, True, fp32_stream), 1)   # fp32_stream: the segmented output projection feeds an fp32 residual
     c = case_inputs(H10_CASE)
     got = torch.load(os.path.join(str(tmp_path), f"o0_{int(fused)}{'_fp8' if fp8_comm else ''}.pt"))
     ref = R.block_forward(c["x"], c["embed0"], c["context"], c["w"], c["cos_sin"], c["heads"])
