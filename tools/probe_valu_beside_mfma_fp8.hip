@@ -23,8 +23,51 @@ __device__ __forceinline__ void ops(float (&e)[8], float (&x)[8], float (&acc)[4
       asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a2) : "v"(pr));
     }
     if constexpr (KIND == 4) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(acc[(J + n) & 3]) : "v"(e[(J + n + 4) & 7]), "v"(e[(J + n + 6) & 7]));
+    // other routes to two e4m3 values: the scaled conversion from fp32; through a packed bf16 / f16 pair
+    if constexpr (KIND == 5) asm volatile("v_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3" : "+v"(pk[(J + n) & 3]) : "v"(e[(J + n + 2) & 7]), "v"(e[(J + n + 5) & 7]), "v"(x[7]));
+    if constexpr (KIND == 6) {
+      int t;
+      asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(t) : "v"(e[(J + n + 2) & 7]), "v"(e[(J + n + 5) & 7]));
+      asm volatile("v_cvt_scalef32_pk_fp8_bf16 %0, %1, %2" : "+v"(pk[(J + n) & 3]) : "v"(t), "v"(x[7]));
+    }
+    if constexpr (KIND == 7) {
+      int t;
+      asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(t) : "v"(e[(J + n + 2) & 7]), "v"(e[(J + n + 5) & 7]));
+      asm volatile("v_cvt_scalef32_pk_fp8_f16 %0, %1, %2" : "+v"(pk[(J + n) & 3]) : "v"(t), "v"(x[7]));
+    }
+    if constexpr (KIND == 8) asm volatile("v_exp_f16 %0, %1" : "=v"(e[(J + n) & 7]) : "v"(x[(J + n) & 7]));
+    if constexpr (KIND == 9) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "+v"(pk[(J + n) & 3]) : "v"(e[(J + n + 2) & 7]), "v"(e[(J + n + 5) & 7]));
     ops<J, N - 1, KIND>(e, x, acc, pk);
   }
+}
+template <int KIND, int N>
+__global__ __launch_bounds__(256) void k1(const int* in, float* out, int iters, long long* cyc) {  // N copies of one instruction kind per gap of the 32x32x64 MFMA
+  const int lane = threadIdx.x & 63;
+  i32x8 a[4], b[4];
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 8; ++j) { a[i][j] = in[(i * 512 + j * 64 + lane) & 4095]; b[i][j] = in[(i * 512 + j * 64 + lane + 2048) & 4095]; }
+  int sa = 127, sb = 127;
+  asm volatile("" : "+v"(sa), "+v"(sb));
+  float x[8], e[8], acc[4] = {0.f, 0.f, 0.f, 0.f};
+  int pk[4] = {};
+  for (int i = 0; i < 8; ++i) { x[i] = -0.01f * (lane + i); e[i] = 0.5f + i; }
+  x[7] = 1.0f;
+  f32x16 c32[4] = {};
+  const long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+    sfor<0, 32>([&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(c32[j & 3]) : "v"(a[j & 3]), "v"(b[(j >> 2) & 3]), "v"(sa), "v"(sb));
+      ops<j, N, KIND>(e, x, acc, pk);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+  const long long t1 = __builtin_readcyclecounter();
+  if (blockIdx.x == 0 && threadIdx.x == 0) cyc[0] = t1 - t0;
+  float r = acc[0] + acc[1] + acc[2] + acc[3];
+  for (int j = 0; j < 4; ++j) for (int q = 0; q < 16; ++q) r += c32[j][q];
+  for (int i = 0; i < 8; ++i) r += e[i];
+  for (int i = 0; i < 4; ++i) r += (float)pk[i];
+  out[blockIdx.x * 256 + threadIdx.x] = r;
 }
 // NA < 0: -NA packed adds instead of adds; NA >= 100: NA - 100 v_max3 instead
 template <int J, int NE, int NA, int NC>
@@ -104,6 +147,15 @@ int main() {
   run(k<0, 4, 4, 2, 2>, "32x32x64 + softmax share + 2 reads");
   run(k<0, 4, 0, 2, 1>, "32x32x64 + 4 exp 2 cvt + 1 read");
   run(k<0, 4, -2, 2, 1>, "32x32x64 + 4 exp 2 pk_add 2 cvt + 1 read");
+  run(k1<2, 2>, "32x32x64 + 2 v_cvt_pk_fp8_f32");
+  run(k1<5, 2>, "32x32x64 + 2 v_cvt_scalef32_pk_fp8_f32");
+  run(k1<6, 2>, "32x32x64 + 2 (cvt_pk_bf16_f32 + cvt_scalef32_pk_fp8_bf16)");
+  run(k1<7, 2>, "32x32x64 + 2 (cvt_pkrtz_f16_f32 + cvt_scalef32_pk_fp8_f16)");
+  run(k1<9, 2>, "32x32x64 + 2 v_cvt_pk_bf16_f32");
+  run(k1<9, 4>, "32x32x64 + 4 v_cvt_pk_bf16_f32");
+  run(k1<0, 4>, "32x32x64 + 4 v_exp_f32");
+  run(k1<8, 4>, "32x32x64 + 4 v_exp_f16");
+  run(k1<1, 4>, "32x32x64 + 4 v_add_f32");
   run(k<1, 0, 0, 0>, "16x16x128 bare");
   run(k<1, 1, 0, 0>, "16x16x128 + 1 exp"); run(k<1, 2, 0, 0>, "16x16x128 + 2 exp"); run(k<1, 3, 0, 0>, "16x16x128 + 3 exp"); run(k<1, 4, 0, 0>, "16x16x128 + 4 exp");
   run(k<1, 2, 2, 1>, "16x16x128 + 2 exp 2 add 1 cvt (one softmax share)");
