@@ -37,6 +37,19 @@ __device__ __forceinline__ void ops(float (&e)[8], float (&x)[8], float (&acc)[4
     }
     if constexpr (KIND == 8) asm volatile("v_exp_f16 %0, %1" : "=v"(e[(J + n) & 7]) : "v"(x[(J + n) & 7]));
     if constexpr (KIND == 9) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "+v"(pk[(J + n) & 3]) : "v"(e[(J + n + 2) & 7]), "v"(e[(J + n + 5) & 7]));
+    // exp-free P: e4m3 code = 8 (x + 7) as an unsigned byte; dependent and independent chains
+    if constexpr (KIND == 10) asm volatile("v_cvt_pk_u8_f32 %0, %1, 1, %0" : "+v"(pk[0]) : "v"(e[(J + n + 2) & 7]));
+    if constexpr (KIND == 11) asm volatile("v_cvt_pk_u8_f32 %0, %1, 1, %0" : "+v"(pk[(J + n) & 3]) : "v"(e[(J + n + 2) & 7]));
+    if constexpr (KIND == 12) asm volatile("v_fmaak_f32 %0, %1, %2, 0x42600000" : "=v"(e[(J + n) & 7]) : "v"(x[7]), "v"(x[(J + n) & 7]));
+    if constexpr (KIND == 13) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(e[(J + n) & 7]) : "v"(x[7]), "v"(x[(J + n) & 7]), "v"(x[6]));
+    if constexpr (KIND == 14) asm volatile("v_cvt_pk_fp8_f32 %0, %1, %2" : "+v"(pk[0]) : "v"(e[(J + n + 2) & 7]), "v"(e[(J + n + 5) & 7]));
+    if constexpr (KIND == 15) asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc[0]) : "v"(e[(J + n + 4) & 7]));
+    if constexpr (KIND == 16) {
+      f32x2 xx = {x[(J + 2 * n) & 6], x[((J + 2 * n) & 6) + 1]}, k8 = {x[7], x[7]}, kb = {x[6], x[6]};
+      f32x2& yy = *reinterpret_cast<f32x2*>(&e[(J + 2 * n) & 6]);
+      asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(yy) : "v"(xx), "v"(k8), "v"(kb));
+    }
+    if constexpr (KIND == 17) asm volatile("v_or_b32 %0, %0, %1" : "+v"(pk[(J + n) & 3]) : "v"(pk[(J + n + 2) & 3]));
     ops<J, N - 1, KIND>(e, x, acc, pk);
   }
 }
@@ -156,6 +169,20 @@ int main() {
   run(k1<0, 4>, "32x32x64 + 4 v_exp_f32");
   run(k1<8, 4>, "32x32x64 + 4 v_exp_f16");
   run(k1<1, 4>, "32x32x64 + 4 v_add_f32");
+  run(k1<10, 4>, "32x32x64 + 4 v_cvt_pk_u8_f32, one chain");
+  run(k1<11, 4>, "32x32x64 + 4 v_cvt_pk_u8_f32, four registers");
+  run(k1<11, 8>, "32x32x64 + 8 v_cvt_pk_u8_f32, four registers");
+  run(k1<12, 4>, "32x32x64 + 4 v_fmaak_f32");
+  run(k1<12, 8>, "32x32x64 + 8 v_fmaak_f32");
+  run(k1<13, 4>, "32x32x64 + 4 v_fma_f32");
+  run(k1<13, 8>, "32x32x64 + 8 v_fma_f32");
+  run(k1<16, 4>, "32x32x64 + 4 v_pk_fma_f32");
+  run(k1<14, 4>, "32x32x64 + 4 v_cvt_pk_fp8_f32, one chain");
+  run(k1<2, 4>, "32x32x64 + 4 v_cvt_pk_fp8_f32, four registers");
+  run(k1<15, 8>, "32x32x64 + 8 v_add_f32, one chain");
+  run(k1<1, 8>, "32x32x64 + 8 v_add_f32, four chains");
+  run(k1<1, 16>, "32x32x64 + 16 v_add_f32, four chains");
+  run(k1<17, 16>, "32x32x64 + 16 v_or_b32");
   run(k<1, 0, 0, 0>, "16x16x128 bare");
   run(k<1, 1, 0, 0>, "16x16x128 + 1 exp"); run(k<1, 2, 0, 0>, "16x16x128 + 2 exp"); run(k<1, 3, 0, 0>, "16x16x128 + 3 exp"); run(k<1, 4, 0, 0>, "16x16x128 + 4 exp");
   run(k<1, 2, 2, 1>, "16x16x128 + 2 exp 2 add 1 cvt (one softmax share)");
