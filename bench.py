@@ -60,6 +60,7 @@ TEXT_DIM = 4096  # umT5-xxl features
 LATENT_CHANNELS = 16
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X
 MFMA_FP8_PEAK_TFLOPS = 5000.0   # dense fp8 (block-scaled e4m3)
+ATTN_TYPES = {"bf16": "hip_flash_attn", "fp8": "hip_fp8_attn", "fp8-linear": "hip_fp8_attn_linear"}
 GUIDE_SCALE = 5.0
 
 
@@ -285,8 +286,8 @@ def arithmetic_label(args):
     if args.linear == "bf16" and args.attn == "bf16":
         return "bf16", ""
     lin = {"bf16": "bf16 Linears", "fp8": "fp8 Linears (W8A8 e4m3)", "int8": "int8 Linears (W8A8)"}[args.linear]
-    att = "bf16 attention" if args.attn == "bf16" else "fp8 attention (block-scaled e4m3)"
-    return f"{lin} + {att}", " (" + ", ".join(x for x in (f"{args.linear} Linears" if args.linear != "bf16" else "", "fp8 attention" if args.attn == "fp8" else "") if x) + ")"
+    att = {"bf16": "bf16 attention", "fp8": "fp8 attention (block-scaled e4m3)", "fp8-linear": "fp8 attention (block-scaled e4m3, exp-free P)"}[args.attn]
+    return f"{lin} + {att}", " (" + ", ".join(x for x in (f"{args.linear} Linears" if args.linear != "bf16" else "", {"bf16": "", "fp8": "fp8 attention", "fp8-linear": "fp8 attention with exp-free P"}[args.attn]) if x) + ")"
 
 
 def run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu):
@@ -313,7 +314,7 @@ def run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu):
     C, TEXT_DIM, TXT_TOKENS, BYT5_TOKENS, VIS_TOKENS = 32, 3584, 1000, 256, 729
     cfg = {"mm_double_blocks_depth": layers, "heads_num": H, "hidden_size": D, "task": "t2v", "patch_size": (1, 1, 1), "out_channels": C,
            "dit_quant_scheme": {"bf16": "hip-bf16", "fp8": "hip-fp8", "int8": "hip-int8"}[args.linear],
-           "attn_type": "hip_flash_attn" if args.attn == "bf16" else "hip_fp8_attn",
+           "attn_type": ATTN_TYPES[args.attn],
            "seq_parallel": seq_p > 1 or args.sp1, "seq_p_group": seq_group, "parallel": {"seq_p_size": seq_p, "seq_p_attn_type": "hip_ulysses"},
            "enable_cfg": False, "sample_guide_scale": -1.0, "sample_shift": 5.0, "infer_steps": 4, "denoising_step_list": [1000, 750, 500, 250],
            "rope_dim_list": [16, 56, 56], "rope_theta": 256.0, "run_device": str(dev)}
@@ -448,8 +449,9 @@ def main():
     ap.add_argument("--layers", type=int, default=None, help="override the layer count (debug only; the JSON line then says so)")
     ap.add_argument("--linear", default="bf16", choices=["bf16", "fp8", "int8"],
                     help="arithmetic of the blocks' Linears: bf16 (the headline configuration), W8A8 e4m3 (the reference's fp8 schemes) or W8A8 int8 (its int8 schemes)")
-    ap.add_argument("--attn", default="bf16", choices=["bf16", "fp8"],
-                    help="self-attention arithmetic: bf16 (the headline configuration) or block-scaled e4m3 on the fp8 MFMA (where the reference would run a quantised backend)")
+    ap.add_argument("--attn", default="bf16", choices=["bf16", "fp8", "fp8-linear"],
+                    help="self-attention arithmetic: bf16 (the headline configuration), block-scaled e4m3 on the fp8 MFMA (where the reference would run a quantised backend), "
+                         "or the same with P taken as 2^x with a linear mantissa instead of by exps")
     ap.add_argument("--residual", default="bf16", choices=["bf16", "fp32"],
                     help="storage of the residual stream between the Linears: bf16 (the headline configuration) or fp32 (the reference's SENSITIVE_LAYER_DTYPE=FP32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -529,7 +531,7 @@ def main():
            "in_dim": LATENT_CHANNELS, "out_dim": LATENT_CHANNELS, "freq_dim": 256, "infer_steps": 50, "sample_shift": 5.0,
            "sample_guide_scale": GUIDE_SCALE, "enable_cfg": True, "run_device": "cuda",
            "dit_quant_scheme": {"bf16": "hip-bf16", "fp8": "hip-fp8", "int8": "hip-int8"}[args.linear],
-           "self_attn_1_type": "hip_flash_attn" if args.attn == "bf16" else "hip_fp8_attn",
+           "self_attn_1_type": ATTN_TYPES[args.attn],
            "sensitive_layer_dtype": "fp32" if args.residual == "fp32" else "bf16",
            "cfg_parallel": cfg_p > 1, "cfg_p_group": cfg_group,
            "seq_parallel": seq_p > 1 or args.sp1, "seq_p_group": seq_group, "parallel": {"seq_p_size": seq_p, "cfg_p_size": cfg_p, "seq_p_attn_type": "hip_ulysses"}}

@@ -49,6 +49,12 @@ constexpr int LDS_BYTES = NSLOT * (K_PART + V_PART);  // 102912
 constexpr int DMA_PER_PERIOD = (F8W4_ABL & 64) ? 4 : 6;                    // per wave: 2 K rows, 1 K scales, 2 V^T rows, 1 V scales
 constexpr float kMaxLaneSum = 64.0f;
 
+// The fragment ring lives in a[224:255] by name: data flows from the reads that fill a slot to the
+// MFMAs that consume it without the compiler seeing a value, so between the two it takes the
+// registers for free and may park a spilled value there.  Every statement the gaps are made of
+// names the whole ring as clobbered: nothing that lives across a gap can then be placed in it.
+// a[216:218] belong to it as well: under LIN the scale dwords of the next tiles land there.
+#define F8_RING_CLOBBERS "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
 // ---- the fragment ring: a[224 + 8 slot + 4 half ..] ----
 template <int SLOT, int HALF, int OFF>
 LX2V_DEVICE void ring_read(uint32_t addr) {
@@ -67,11 +73,17 @@ LX2V_DEVICE void ring_read(uint32_t addr) {
 }
 
 // S (VGPR) = K fragment (ring) x Q^T (AGPR) + (-m) (VGPR) for the first 64 channels, += for the others.
+// TIED: the first step names S as read and written although it only writes it: a score tuple is then one
+// value from the prologue to the end and keeps its registers, instead of a new value per tile that the
+// compiler may place elsewhere and move there -- with a copy it could put right behind an MFMA
+// whose result it believes to be there already.
 // Scale bytes: byte ks of the K scale dword and of the Q scale dword.
-template <int SLOT, int KS>
+template <int SLOT, int KS, bool TIED>
 LX2V_DEVICE void mfma_qk(f32x16& s, const i32x8& qf, const f32x16& negm, int ksc, int qsc) {
 #define F8_QK(S, REGS)                                                                                                                  \
-  if constexpr (SLOT == S && KS == 0)                                                                                                   \
+  if constexpr (SLOT == S && KS == 0 && TIED)                                                                                           \
+    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, " REGS ", %1, %2, %3, %4 op_sel_hi:[0,0,0]" : "+v"(s) : "a"(qf), "v"(negm), "v"(ksc), "v"(qsc)); \
+  if constexpr (SLOT == S && KS == 0 && !TIED)                                                                                          \
     asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, " REGS ", %1, %2, %3, %4 op_sel_hi:[0,0,0]" : "=&v"(s) : "a"(qf), "v"(negm), "v"(ksc), "v"(qsc)); \
   if constexpr (SLOT == S && KS == 1)                                                                                                   \
     asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, " REGS ", %1, %0, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,0,0]" : "+v"(s) : "a"(qf), "v"(ksc), "v"(qsc))
@@ -104,6 +116,26 @@ template <int N>
 LX2V_DEVICE void wait_lds() {
   static_assert(N >= 0 && N <= 15, "lgkmcnt");
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N));
+}
+
+// A scale dword read that the compiler gets no value from: it lands in a[216 + SLOT] (K block 0, K
+// block 1, V) and is fetched by scale_fetch behind the wait that covers it.  (As a "=v" output the
+// compiler holds a value from the moment the read is ISSUED, and under register pressure parks it in
+// another register at once -- taking what the register held before the data landed.)
+template <int SLOT, int OFF>
+LX2V_DEVICE void scale_read_named(uint32_t addr) {
+  static_assert(OFF >= 0 && OFF < 65536 && SLOT >= 0 && SLOT < 3, "ds offset / slot");
+  if constexpr (SLOT == 0) asm volatile("ds_read_b32 a216, %0 offset:%1" ::"v"(addr), "i"(OFF) : "a216");
+  if constexpr (SLOT == 1) asm volatile("ds_read_b32 a217, %0 offset:%1" ::"v"(addr), "i"(OFF) : "a217");
+  if constexpr (SLOT == 2) asm volatile("ds_read_b32 a218, %0 offset:%1" ::"v"(addr), "i"(OFF) : "a218");
+}
+template <int SLOT>
+LX2V_DEVICE int scale_fetch() {
+  int r;
+  if constexpr (SLOT == 0) asm volatile("v_accvgpr_read_b32 %0, a216" : "=v"(r));
+  if constexpr (SLOT == 1) asm volatile("v_accvgpr_read_b32 %0, a217" : "=v"(r));
+  if constexpr (SLOT == 2) asm volatile("v_accvgpr_read_b32 %0, a218" : "=v"(r));
+  return r;
 }
 
 template <int OFF>
@@ -144,7 +176,35 @@ LX2V_DEVICE uint32_t sum_cvt4_op(float& ls, const float (&e)[4]) {
   return pk;
 }
 
-template <bool SHORT_KV>
+// ---- LIN: P without an exp ----
+// An e4m3 code read as an integer is 8 (exponent + 7) + mantissa: a piecewise linear image of
+// 8 (log2 + 7), with the subnormal codes continuing the line.  With the scores delivered by the QK
+// MFMAs as 8 (s - m) + 56 (the Q scale bytes raised by 3, the accumulator init -8 m + 56), P is one
+// saturating float -> byte conversion per score: 2^x with the mantissa taken linearly, at most 8.6 %
+// above 2^x and 4.3 % on average -- a common factor that the row sums, taken over the same codes,
+// divide out; what is left is an error of +-0.35 code that depends on the fraction of x, beside the
+// +-0.5 code of the rounding every e4m3 P carries.
+LX2V_DEVICE uint32_t cvt4_u8_op(float s0, float s1, float s2, float s3) {
+  uint32_t pk;
+  asm volatile("v_cvt_pk_u8_f32 %0, %1, 0, 0\n\tv_cvt_pk_u8_f32 %0, %2, 1, %0\n\tv_cvt_pk_u8_f32 %0, %3, 2, %0\n\tv_cvt_pk_u8_f32 %0, %4, 3, %0"
+               : "=&v"(pk)
+               : "v"(s0), "v"(s1), "v"(s2), "v"(s3)
+               : F8_RING_CLOBBERS);
+  return pk;
+}
+LX2V_DEVICE void or_op(uint32_t& acc, uint32_t v) { asm volatile("v_or_b32 %0, %0, %1" : "+v"(acc) : "v"(v) : F8_RING_CLOBBERS); }
+// Row sums on the MFMA pipe: lsum (accumulator file) += SEL x P^T, SEL a constant 16 x 128 operand
+// whose rows 0-7 are ones on k-blocks 0 and 2 and rows 8-15 ones on k-blocks 1 and 3.  P is laid out
+// for the 32x32x64 B operand (lane = row mod 32, k-block = lane / 32), which this shape reads as
+// column lane & 15, k-block lane / 16: lanes 0-31 end up with the sum of row lane & 15, lanes 32-63
+// with that of row 16 + (lane & 15), in all four registers.
+LX2V_DEVICE void mfma_rowsum(f32x4& lsum, const i32x8& sel, const i32x8& pf, int unit) {
+  asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+a"(lsum) : "a"(sel), "v"(pf), "v"(unit) : F8_RING_CLOBBERS);
+}
+constexpr float kLinOne = 56.0f;       // code of P = 1
+constexpr float kLinMaxTileSum = 256.0f;  // a tile that adds less than this to a row's sum holds no P at or above 2^8 (e4m3 ends at 448)
+
+template <bool SHORT_KV, bool LIN>
 __global__ __launch_bounds__(F8_THREADS) void attn_fwd_fp8_w4_kernel(const Fp8AttnParams p, const RoundSync rs) {
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
   round_enter(rs);
@@ -173,6 +233,7 @@ __global__ __launch_bounds__(F8_THREADS) void attn_fwd_fp8_w4_kernel(const Fp8At
     }
     const uint32_t sc = *reinterpret_cast<const uint32_t*>(p.qs + ((int64_t)qrow_c * p.heads + head) * 4);
     qsc[qb] = (int)(((sc >> (8 * h)) & 0xffu) | (((sc >> (8 * (2 + h))) & 0xffu) << 8));  // byte ks = scale of block 2 ks + h
+    if constexpr (LIN) qsc[qb] += 0x0303;  // scores times 8 (the scale bytes are exponents; Q scales sit far below 252)
   }
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb)
@@ -275,10 +336,20 @@ __global__ __launch_bounds__(F8_THREADS) void attn_fwd_fp8_w4_kernel(const Fp8At
   int ksc[2] = {0, 0}, vsc = 0;
   int unit = UNIT_SCALE;
   asm volatile("" : "+v"(unit));
+  // LIN: row sums in the accumulator file (see mfma_rowsum), their value before the tile in flight, the constant operand
+  f32x4 lsum[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  float lprev[2] = {0.f, 0.f};
+  i32x8 sel;
+  if constexpr (LIN) {
+    const int one4 = (((lane & 15) < 8) == (((lane >> 4) & 1) == 0)) ? 0x38383838 : 0;  // e4m3 1.0 in every byte, or nothing
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sel[i] = one4;
+    asm volatile("" : "+a"(sel), "+a"(lsum[0]), "+a"(lsum[1]));
+  }
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) negm[qb][i] = 0.f;
+    for (int i = 0; i < 16; ++i) negm[qb][i] = LIN ? kLinOne : 0.f;
     asm volatile("" : "+v"(negm[qb]));
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
@@ -321,9 +392,17 @@ __global__ __launch_bounds__(F8_THREADS) void attn_fwd_fp8_w4_kernel(const Fp8At
 #pragma unroll
     for (int i = 1; i < 32; ++i) mx = fmaxf(mx, sc[i >> 4][qb][i & 15]);
     mx = half_swap_max(mx);
+    if constexpr (LIN) mx -= kLinOne;  // scores are 8 (s - m) + 56 here, delta is in the same eighths
     const float delta = first ? mx : fmaxf(mx, 0.f);
-    const float alpha = __builtin_amdgcn_exp2f(-delta);
+    const float alpha = __builtin_amdgcn_exp2f(LIN ? -0.125f * delta : -delta);
     l_run[qb] *= alpha;
+    if constexpr (LIN) {  // the row sums go back to their value before this tile, scaled; the tile is added again below
+      const int lsum_row = (threadIdx.x & 15) + ((threadIdx.x >> 1) & 16);  // the row whose sum this lane's lsum holds (a lane of the same h: it has that row's alpha)
+      const float base = lprev[qb] * __shfl(alpha, lsum_row, 64);
+      asm volatile("s_nop 7\n\ts_nop 7" : "+a"(lsum[qb]));
+      lsum[qb] = f32x4{base, base, base, base};
+      asm volatile("" : "+a"(lsum[qb]));
+    }
     static_for<0, 4>([&](auto dbc) __attribute__((always_inline)) {  // one tuple at a time through the architectural file
       constexpr int db = decltype(dbc)::value;
 #pragma unroll
@@ -343,13 +422,24 @@ __global__ __launch_bounds__(F8_THREADS) void attn_fwd_fp8_w4_kernel(const Fp8At
         for (int j = 0; j < 4; ++j) {
           sc[kb][qb][4 * w + j] -= delta;
           sn[kb][qb][4 * w + j] -= delta;
-          e[j] = __builtin_amdgcn_exp2f(sc[kb][qb][4 * w + j]);
-          ls += e[j];
+          if constexpr (!LIN) {
+            e[j] = __builtin_amdgcn_exp2f(sc[kb][qb][4 * w + j]);
+            ls += e[j];
+          }
         }
-        int pk = __builtin_amdgcn_cvt_pk_fp8_f32(e[0], e[1], 0, false);
-        pc[4 * kb + w] = __builtin_amdgcn_cvt_pk_fp8_f32(e[2], e[3], pk, true);
+        if constexpr (LIN) {
+          pc[4 * kb + w] = (int)cvt4_u8_op(sc[kb][qb][4 * w], sc[kb][qb][4 * w + 1], sc[kb][qb][4 * w + 2], sc[kb][qb][4 * w + 3]);
+        } else {
+          int pk = __builtin_amdgcn_cvt_pk_fp8_f32(e[0], e[1], 0, false);
+          pc[4 * kb + w] = __builtin_amdgcn_cvt_pk_fp8_f32(e[2], e[3], pk, true);
+        }
       }
     asm volatile("s_nop 1" : "+a"(o[qb][0]), "+a"(o[qb][1]), "+a"(o[qb][2]), "+a"(o[qb][3]), "+v"(negm[qb]), "+v"(pc), "+v"(sn[0][qb]), "+v"(sn[1][qb]));
+    if constexpr (LIN) {
+      mfma_rowsum(lsum[qb], sel, pc, unit);
+      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+a"(lsum[qb]));
+      lprev[qb] = lsum[qb][0];
+    }
   };
 
   // One period.  TM = t mod 6 fixes every buffer: S / P parity TM & 1, K slot (TM + 1) % 6, V slot
@@ -362,6 +452,8 @@ __global__ __launch_bounds__(F8_THREADS) void attn_fwd_fp8_w4_kernel(const Fp8At
     i32x8 (&Pc)[2] = pf[PAR];          // P(t): produced
     i32x8 (&Pp)[2] = pf[PAR ^ 1];      // P(t-1): consumed
     float ls[2] = {0.f, 0.f};
+    uint32_t orv = 0;  // LIN: the P dwords of the tile or-ed together
+    asm volatile("" : "+v"(orv));
     float e[2][4];  // exps of the dword of this gap / of the previous one
     if ((t + 1) * KVB > p.skv) mask_tile(Sc, t * KVB);  // wave-uniform: the last real tile when ragged, and the tile past the end
     int ksc_next[2] = {0, 0}, vsc_next = 0;
@@ -384,11 +476,22 @@ __global__ __launch_bounds__(F8_THREADS) void attn_fwd_fp8_w4_kernel(const Fp8At
       // fragment F has landed: reads issued behind it are those of fragments F + 1 and F + 2 (two
       // each) and the scale reads that precede K00 (two) and V0 (one) of the next period
       if constexpr (!(F8W4_ABL & (2 | 32))) wait_lds<4 + (F == 0 ? 1 : F == 6 ? 2 : F == 7 ? 3 : 0)>();
+      if constexpr (LIN) {  // the wait of step 0 covers the K scale dwords of this period, that of step 1 the V scales
+        if constexpr (F == 0) {
+          ksc[0] = scale_fetch<0>();
+          ksc[1] = scale_fetch<1>();
+          asm volatile("s_nop 1" : "+v"(ksc[0]), "+v"(ksc[1]));
+        }
+        if constexpr (F == 1) {
+          vsc = scale_fetch<2>();
+          asm volatile("s_nop 1" : "+v"(vsc));
+        }
+      }
       static_for<0, 2>([&](auto qbc) __attribute__((always_inline)) {
         constexpr int qb = decltype(qbc)::value, G = 2 * F + qb;
         if constexpr ((F & 1) == 0) {
           constexpr int kb = (F >> 1) & 1, ks = F >> 2;
-          mfma_qk<(F & 3), ks>(Sn[kb][qb], qf[qb][ks], negm[qb], ksc[kb], qsc[qb]);
+          mfma_qk<(F & 3), ks, LIN>(Sn[kb][qb], qf[qb][ks], negm[qb], ksc[kb], qsc[qb]);
         } else {
           mfma_pv<(F & 3), (F >> 1)>(o[qb][F >> 1], Pp[qb], vsc, unit);
         }
@@ -399,17 +502,39 @@ __global__ __launch_bounds__(F8_THREADS) void attn_fwd_fp8_w4_kernel(const Fp8At
           frag_read(tmc, IntC<F + 3>{}, qbc);
         } else {
           if constexpr (!(F8W4_ABL & 2)) {
-            if constexpr (F == 5 && qb == 0) {
-              ksc_next[0] = scale_read<K_RING + ((TM + 2) % NSLOT) * K_PART>(ks_rd);
-              ksc_next[1] = scale_read<K_RING + ((TM + 2) % NSLOT) * K_PART + 256>(ks_rd);
+            if constexpr (LIN) {
+              if constexpr (F == 5 && qb == 0) {
+                scale_read_named<0, K_RING + ((TM + 2) % NSLOT) * K_PART>(ks_rd);
+                scale_read_named<1, K_RING + ((TM + 2) % NSLOT) * K_PART + 256>(ks_rd);
+              }
+              if constexpr (F == 6 && qb == 0) scale_read_named<2, (TM % NSLOT) * V_PART>(vs_rd);
+            } else {
+              if constexpr (F == 5 && qb == 0) {
+                ksc_next[0] = scale_read<K_RING + ((TM + 2) % NSLOT) * K_PART>(ks_rd);
+                ksc_next[1] = scale_read<K_RING + ((TM + 2) % NSLOT) * K_PART + 256>(ks_rd);
+              }
+              if constexpr (F == 6 && qb == 0) vsc_next = scale_read<(TM % NSLOT) * V_PART>(vs_rd);
             }
-            if constexpr (F == 6 && qb == 0) vsc_next = scale_read<(TM % NSLOT) * V_PART>(vs_rd);
           }
           frag_read(IntC<(TM + 1) % NSLOT>{}, IntC<F - 5>{}, qbc);
         }
         if constexpr (F >= 5 && !(F8W4_ABL & 4)) dma_piece_go(IntC<2 * (F - 5) + qb>{}, k_soff, v_soff);
+        // LIN: the sixteen P dwords are conversions of the scores, two per gap in gaps 0-3 (block 0) and one
+        // per gap in gaps 4-11 (block 1), which keeps them out of the gaps that also stage; each block's
+        // row-sum MFMA follows a gap later, behind that gap's VALU work (right behind the gap's own MFMA
+        // it would hold the wave until that one has left the pipe).
+        if constexpr (LIN && !(F8W4_ABL & 1)) {
+          constexpr int D0 = G < 4 ? 2 * G : G < 12 ? G + 4 : -1, ND = G < 4 ? 2 : G < 12 ? 1 : 0;
+          static_for<0, ND>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int D = D0 + decltype(ic)::value, dq = D >> 3, dkb = (D >> 2) & 1, dw = D & 3;
+            Pc[dq][D & 7] = (int)cvt4_u8_op(Sc[dkb][dq][4 * dw], Sc[dkb][dq][4 * dw + 1], Sc[dkb][dq][4 * dw + 2], Sc[dkb][dq][4 * dw + 3]);
+            or_op(orv, (uint32_t)Pc[dq][D & 7]);
+          });
+          if constexpr (G == 5) mfma_rowsum(lsum[0], sel, Pc[0], unit);
+          if constexpr (G == 12) mfma_rowsum(lsum[1], sel, Pc[1], unit);
+        }
         // softmax share of gap G: exps of dword G, consumers of dword G - 1
-        if constexpr (!(F8W4_ABL & 1)) {
+        if constexpr (!LIN && !(F8W4_ABL & 1)) {
           constexpr int dq = G >> 3, dkb = (G >> 2) & 1, dw = G & 3;
           if constexpr (F8W4_ABL & 256) {
 #pragma unroll
@@ -427,22 +552,40 @@ __global__ __launch_bounds__(F8_THREADS) void attn_fwd_fp8_w4_kernel(const Fp8At
         __builtin_amdgcn_sched_barrier(0);
       });
     });
-    ksc[0] = ksc_next[0];
-    ksc[1] = ksc_next[1];
-    vsc = vsc_next;
+    if constexpr (!LIN) {
+      ksc[0] = ksc_next[0];
+      ksc[1] = ksc_next[1];
+      vsc = vsc_next;
+    }
     // ---- consumers of the last dword, then the overflow check of tile t, before any P(t) is used ----
-    if constexpr (!(F8W4_ABL & 1)) {
+    if constexpr (!LIN && !(F8W4_ABL & 1)) {
       ls[1] += (e[1][0] + e[1][1]) + (e[1][2] + e[1][3]);
       int pk = __builtin_amdgcn_cvt_pk_fp8_f32(e[1][0], e[1][1], 0, false);
       Pc[1][7] = __builtin_amdgcn_cvt_pk_fp8_f32(e[1][2], e[1][3], pk, true);
     }
     asm volatile("" : "+v"(Pc[0]), "+v"(Pc[1]), "+v"(ls[0]), "+v"(ls[1]));
     const bool first = t == 0;  // tile 0: m becomes its true row maximum
-    if (!(F8W4_ABL & 16) && __builtin_expect(first || __any(!(fmaxf(ls[0], ls[1]) <= kMaxLaneSum)), 0)) {
-      static_for<0, 2>([&](auto qbc) __attribute__((always_inline)) { fixup(qbc, Sc, Sn, Pc[decltype(qbc)::value], first, ls[decltype(qbc)::value]); });
+    if constexpr (LIN) {
+      // What the tile added to each row's sum (the row-sum MFMAs were issued three and ten gaps ago; the
+      // wait states cover the architectural minimum all the same).  A P at or above 2^8 -- e4m3 ends at
+      // 448, the code after it is NaN, saturated conversions read as negative numbers -- shows as an
+      // increase of at least 2^8, as a NaN, or as a code with the sign bit.
+      asm volatile("s_nop 7\n\ts_nop 3" : "+a"(lsum[0]), "+a"(lsum[1]));
+      const float l0 = lsum[0][0], l1 = lsum[1][0];
+      const bool over = __any(!(l0 - lprev[0] < kLinMaxTileSum) || !(l1 - lprev[1] < kLinMaxTileSum) || (orv & 0x80808080u) != 0);
+      if (!(F8W4_ABL & 16) && __builtin_expect(first || over, 0)) {
+        static_for<0, 2>([&](auto qbc) __attribute__((always_inline)) { fixup(qbc, Sc, Sn, Pc[decltype(qbc)::value], first, ls[decltype(qbc)::value]); });
+      } else {
+        lprev[0] = l0;
+        lprev[1] = l1;
+      }
+    } else {
+      if (!(F8W4_ABL & 16) && __builtin_expect(first || __any(!(fmaxf(ls[0], ls[1]) <= kMaxLaneSum)), 0)) {
+        static_for<0, 2>([&](auto qbc) __attribute__((always_inline)) { fixup(qbc, Sc, Sn, Pc[decltype(qbc)::value], first, ls[decltype(qbc)::value]); });
+      }
+      l_run[0] += ls[0];
+      l_run[1] += ls[1];
     }
-    l_run[0] += ls[0];
-    l_run[1] += ls[1];
   };
 
   // ---- prologue: K(0..5) and V(0..3) staged; the V slots of the tiles "-2" and "-1" (4 and 5) zeroed
@@ -463,13 +606,17 @@ __global__ __launch_bounds__(F8_THREADS) void attn_fwd_fp8_w4_kernel(const Fp8At
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   // fragments 0..2 and the scales of the first period (t = -1: K(0) in slot 0, "V(-2)" in slot 4)
-  if constexpr (!(F8W4_ABL & 2)) {
+  if constexpr (LIN) {
+    scale_read_named<0, K_RING>(ks_rd);
+    scale_read_named<1, K_RING + 256>(ks_rd);
+  } else if constexpr (!(F8W4_ABL & 2)) {
     ksc[0] = scale_read<K_RING>(ks_rd);
     ksc[1] = scale_read<K_RING + 256>(ks_rd);
   }
   frag_read(IntC<5>{}, IntC<0>{}, IntC<0>{});
   frag_read(IntC<5>{}, IntC<0>{}, IntC<1>{});
-  if constexpr (!(F8W4_ABL & 2)) vsc = scale_read<4 * V_PART>(vs_rd);
+  if constexpr (LIN) scale_read_named<2, 4 * V_PART>(vs_rd);
+  else if constexpr (!(F8W4_ABL & 2)) vsc = scale_read<4 * V_PART>(vs_rd);
   frag_read(IntC<5>{}, IntC<1>{}, IntC<0>{});
   frag_read(IntC<5>{}, IntC<1>{}, IntC<1>{});
   frag_read(IntC<5>{}, IntC<2>{}, IntC<0>{});
@@ -497,13 +644,24 @@ __global__ __launch_bounds__(F8_THREADS) void attn_fwd_fp8_w4_kernel(const Fp8At
   round_leave(rs);
 
   // ---- normalise and store ----
+  // (lane and row numbers once more from a register the loop keeps anyway: kept alive from the
+  // prologue they cost the loop registers it does not have)
+  const int lane_e = dma_voff >> 4, r32_e = lane_e & 31, h_e = lane_e >> 5;
+  const int q0_e = qb_wg * QROWS + (int)wid_u * 64;
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+a"(o[qb][0]), "+a"(o[qb][1]), "+a"(o[qb][2]), "+a"(o[qb][3]));
-    const float inv = 1.0f / half_swap_sum(l_run[qb]);
-    const int qrow = q0 + 32 * qb + r32;
+    float lrow;
+    if constexpr (LIN) {
+      asm volatile("s_nop 7\n\ts_nop 7" : "+a"(lsum[qb]));
+      lrow = __shfl(lsum[qb][0], r32_e < 16 ? r32_e : r32_e + 16, 64);
+    } else {
+      lrow = half_swap_sum(l_run[qb]);
+    }
+    const float inv = 1.0f / lrow;
+    const int qrow = q0_e + 32 * qb + r32_e;
     if (qrow < p.sq) {
-      uint16_t* op = p.out + (int64_t)qrow * p.ldo + head * HD + 4 * h;
+      uint16_t* op = p.out + (int64_t)qrow * p.ldo + head * HD + 4 * h_e;
 #pragma unroll
       for (int db = 0; db < 4; ++db)
 #pragma unroll
@@ -519,6 +677,9 @@ __global__ __launch_bounds__(F8_THREADS) void attn_fwd_fp8_w4_kernel(const Fp8At
 
 int lx2v_attn_fp8_launch_w4(const Fp8AttnParams& p, hipStream_t st) {
   // workgroups of one round sweep a head's image together (see attn_w4_common.h)
-  return launch_with_rounds(attn_fwd_fp8_w4_kernel<true>, attn_fwd_fp8_w4_kernel<false>, F8_THREADS, p, (int64_t)p.tiles * TILE_BLOB, (int64_t)p.nqb * p.heads, st,
+  if (lx2v_options().attn_fp8_p == 1)
+    return launch_with_rounds(attn_fwd_fp8_w4_kernel<true, true>, attn_fwd_fp8_w4_kernel<false, true>, F8_THREADS, p, (int64_t)p.tiles * TILE_BLOB, (int64_t)p.nqb * p.heads, st,
+                              "attn_fwd_fp8(w4, linear P)");
+  return launch_with_rounds(attn_fwd_fp8_w4_kernel<true, false>, attn_fwd_fp8_w4_kernel<false, false>, F8_THREADS, p, (int64_t)p.tiles * TILE_BLOB, (int64_t)p.nqb * p.heads, st,
                             "attn_fwd_fp8(w4)");
 }

@@ -41,6 +41,8 @@ void init_options() {
   g_opt.attn_variant = env_int("LX2V_ATTN_VARIANT", 1) != 0;
   const char* f8 = getenv("LX2V_ATTN_FP8_KERNEL");
   g_opt.attn_fp8_kernel = (f8 != nullptr && strcmp(f8, "w8") == 0) ? 8 : 4;
+  const char* f8p = getenv("LX2V_ATTN_FP8_P");
+  g_opt.attn_fp8_p = (f8p != nullptr && strcmp(f8p, "linear") == 0) ? 1 : 0;
   const char* g = getenv("LX2V_GEMM_KERNEL");
   g_opt.gemm_kernel = g == nullptr ? 0 : strcmp(g, "simple") == 0 ? 1 : strcmp(g, "pingpong") == 0 ? 2 : 0;
 }
@@ -53,7 +55,7 @@ const OptName kOptNames[] = {
     {"attn_kernel", &Lx2vOptions::attn_kernel}, {"attn_qb", &Lx2vOptions::attn_qb},
     {"attn_tail", &Lx2vOptions::attn_tail},     {"attn_round_sync", &Lx2vOptions::attn_round_sync},
     {"attn_variant", &Lx2vOptions::attn_variant}, {"gemm_kernel", &Lx2vOptions::gemm_kernel},
-    {"attn_fp8_kernel", &Lx2vOptions::attn_fp8_kernel},
+    {"attn_fp8_kernel", &Lx2vOptions::attn_fp8_kernel}, {"attn_fp8_p", &Lx2vOptions::attn_fp8_p},
 };
 
 }  // namespace
@@ -70,6 +72,7 @@ extern "C" int lx2v_set_option(const char* name, int value) {
     if (strcmp(name, o.name) == 0) {
       if (o.field == &Lx2vOptions::attn_kernel) LX2V_REQUIRE(value == 16 || value == 4 || value == 8, LX2V_EINVAL, "set_option: attn_kernel must be 16, 4 or 8");
       if (o.field == &Lx2vOptions::attn_fp8_kernel) LX2V_REQUIRE(value == 4 || value == 8, LX2V_EINVAL, "set_option: attn_fp8_kernel must be 4 or 8");
+      if (o.field == &Lx2vOptions::attn_fp8_p) LX2V_REQUIRE(value == 0 || value == 1, LX2V_EINVAL, "set_option: attn_fp8_p must be 0 (exact) or 1 (linear)");
       if (o.field == &Lx2vOptions::attn_qb) LX2V_REQUIRE(value == 0 || value == 4 || value == 5, LX2V_EINVAL, "set_option: attn_qb must be 0, 4 or 5");
       g_opt.*(o.field) = value;
       return LX2V_OK;

@@ -66,6 +66,7 @@ struct Lx2vOptions {
   int attn_round_sync;  // LX2V_ATTN_ROUND_SYNC=0: no round alignment (a locality hint: same results)
   int attn_variant;     // LX2V_ATTN_VARIANT=0: 8-wave kernel without pipelined K-fragment reads
   int attn_fp8_kernel;  // LX2V_ATTN_FP8_KERNEL=w4|w8 -> 4 (default: one wave per SIMD), 8
+  int attn_fp8_p;       // LX2V_ATTN_FP8_P=linear -> 1: the one-wave-per-SIMD fp8 kernel takes P = 2^x with a linear mantissa, without exps (faster, see attn_fp8_w4.hip); 0 = exact exps (default)
   int gemm_kernel;      // LX2V_GEMM_KERNEL=simple|pingpong -> 1 | 2; 0 = each GEMM's default (bf16: persistent one-wave-per-SIMD kernel, fp8: simple)
 };
 const Lx2vOptions& lx2v_options();

@@ -45,12 +45,21 @@ def mx_dequant(q: torch.Tensor, e8: torch.Tensor, dim: int = -1) -> torch.Tensor
     return xb.reshape(shp).movedim(-1, dim)
 
 
-def attention_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float | None = None) -> torch.Tensor:
+def linear_p(x: torch.Tensor) -> torch.Tensor:
+    """2^x with the mantissa taken linearly, as the e4m3 value whose code is 8 (x + 7) rounded to nearest
+    even and clamped to a byte (a code is 8 (exponent + 7) + mantissa; codes below 8 are subnormals and
+    continue the line): the kernel's P under `attn_fp8_p = 1`, for x <= 0."""
+    code = torch.clamp(torch.round(8.0 * x + 56.0), 0, 255).to(torch.uint8)
+    return code.view(torch.float8_e4m3fn).float()
+
+
+def attention_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float | None = None, p_mode: str = "exact") -> torch.Tensor:
     """q [Sq,H,d], k/v [Skv,H,d] (bf16 values) -> [Sq, H*d] fp32 with the kernel's quantisation:
     q*scale*log2(e) and k block-quantised over channels, v block-quantised over groups of 32
     consecutive keys per channel, P = exp2(s - rowmax) rounded to e4m3 for the numerator, the row sum taken over
     the unrounded values.  (The kernel's running maximum lags the true one by up to 2^6, so its P is this P times a
-    per-row factor before rounding: same distribution of rounding errors, not the same bits.)"""
+    per-row factor before rounding: same distribution of rounding errors, not the same bits.)
+    p_mode "linear": P = linear_p(s - rowmax) in the numerator and in the row sum."""
     sq, H, d = q.shape
     skv = k.shape[0]
     if scale is None:
@@ -62,6 +71,10 @@ def attention_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: floa
     vp[:skv] = v.float()
     vd = mx_dequant(*mx_quant(vp, dim=0), dim=0)[:skv]
     s = torch.einsum("qhd,khd->hqk", qd, kd)
+    if p_mode == "linear":
+        p = linear_p(s - s.amax(-1, keepdim=True))
+        o = torch.einsum("hqk,khd->qhd", p, vd) / p.sum(-1).transpose(0, 1)[..., None]
+        return o.reshape(sq, H * d)
     p = torch.exp2(s - s.amax(-1, keepdim=True))
     o = torch.einsum("hqk,khd->qhd", p.to(torch.float8_e4m3fn).float(), vd) / p.sum(-1).transpose(0, 1)[..., None]
     return o.reshape(sq, H * d)

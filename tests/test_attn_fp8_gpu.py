@@ -88,6 +88,70 @@ def test_fp8_attention_peaked_scores_and_strided_inputs(cuda):
     assert torch.isfinite(out).all()
 
 
+@pytest.fixture
+def linear_p():
+    """`attn_fp8_p = 1` for the test: P = 2^x with a linear mantissa (no exps), row sums over the same codes."""
+    hip.set_option("attn_fp8_p", 1)
+    try:
+        yield
+    finally:
+        hip.set_option("attn_fp8_p", 0)
+
+
+@pytest.mark.parametrize("sq,skv,H", [(64, 64, 1), (300, 300, 2), (257, 512, 3), (1000, 1000, 2), (96, 77, 2), (300, 1700, 1), (64, 896, 1)])
+def test_fp8_attention_with_linear_p(cuda, linear_p, sq, skv, H):
+    """The exp-free P costs accuracy against the fp32 softmax in the fourth digit of the cosine (the linear
+    mantissa is off by up to 0.35 code beside the 0.5 code of e4m3 rounding).  Against the emulation of the
+    same rule the kernel agrees to the last digit while its running maximum is the true one (one tile);
+    with more tiles the maximum it rounds under lags, and both the rounding and the linear-mantissa error
+    fall differently (cosine ~0.999)."""
+    q, k, v = _qkv(sq, skv, H, 500 + sq)
+    out = hip.attn_fwd_fp8(q.to(cuda), k.to(cuda), v.to(cuda)).float().cpu()
+    ref = R.sdpa(q.float(), k.float(), v.float())
+    emu = A8.attention_fp8(q, k, v, p_mode="linear")
+    rel_rms = ((out - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    print(f"\nfp8 attn, linear P, sq={sq} skv={skv} H={H}: cos vs fp32 {cos(out, ref):.6f} (emulation vs fp32 {cos(emu, ref):.6f}), cos vs emulation {cos(out, emu):.6f}, rel rms {rel_rms:.4f}")
+    assert torch.isfinite(out).all()
+    assert cos(out, ref) >= 0.998 and rel_rms <= 0.065
+    # one tile: the kernel's maximum is the emulation's.  More tiles: the emulation, rounding under the TRUE row maximum,
+    # pushes more of a long row's small P into the subnormal codes (where the line is no longer 2^x) than the kernel does
+    # under its lagging maximum, and is the less accurate of the two against the fp32 softmax
+    assert cos(out, emu) >= (0.99999 if skv <= 64 else 0.997)
+    assert cos(out, ref) >= cos(emu, ref) - 2e-4
+
+
+def test_fp8_attention_with_linear_p_peaked_scores(cuda, linear_p):
+    """Score spread of 6: later tiles exceed the running maximum by more than 2^8 for some rows, so the
+    check on the row-sum increase fires and the rare path re-bases (and re-adds the tile's row sums)."""
+    S, H = 700, 2
+    q, k, v = _qkv(S, S, H, 77, spread=2.5)
+    out = hip.attn_fwd_fp8(q.to(cuda), k.to(cuda), v.to(cuda)).float().cpu()
+    ref = R.sdpa(q.float(), k.float(), v.float())
+    emu = A8.attention_fp8(q, k, v, p_mode="linear")
+    print(f"\npeaked scores, linear P: cos vs fp32 {cos(out, ref):.6f} (emulation vs fp32 {cos(emu, ref):.6f}), cos vs emulation {cos(out, emu):.6f}")
+    assert torch.isfinite(out).all()
+    assert cos(out, ref) >= 0.99 and cos(out, emu) >= 0.998
+
+
+def test_fp8_attention_with_linear_p_rising_scores(cuda, linear_p):
+    """Keys whose scores rise along the sequence (each tile beats the last by a wide margin): the rare
+    path runs again and again, with increases far beyond e4m3's range in between."""
+    S, H = 640, 1
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(S, H, 128, generator=g)
+    k = torch.randn(S, H, 128, generator=g)
+    ramp = torch.linspace(0.2, 6.0, S)[:, None, None]
+    k = (k * 0.3 + q.mean(0, keepdim=True) * ramp).to(torch.bfloat16)
+    q = q.to(torch.bfloat16)
+    v = torch.randn(S, H, 128, generator=g).to(torch.bfloat16)
+    out = hip.attn_fwd_fp8(q.to(cuda), k.to(cuda), v.to(cuda)).float().cpu()
+    ref = R.sdpa(q.float(), k.float(), v.float())
+    emu = A8.attention_fp8(q, k, v, p_mode="linear")
+    print(f"\nrising scores, linear P: cos vs fp32 {cos(out, ref):.6f} (emulation vs fp32 {cos(emu, ref):.6f}), cos vs emulation {cos(out, emu):.6f}")
+    assert torch.isfinite(out).all()
+    assert cos(out, ref) >= 0.99 and cos(out, emu) >= 0.995
+
+
 def test_fp8_attention_plugin_and_workspace_checks(cuda):
     q, k, v = _qkv(128, 128, 2, 9)
     plug = L.ATTN_WEIGHT_REGISTER["hip_fp8_attn"]()
@@ -102,14 +166,15 @@ def test_fp8_attention_plugin_and_workspace_checks(cuda):
         plug.apply(q=q.to(cuda), k=k.to(cuda), v=v.to(cuda), causal=True)
 
 
-def test_block_with_fp8_attention_meets_the_block_gate(cuda):
-    """Wan block with `self_attn_1_type = hip_fp8_attn` against the reference's fp32 run: output cosine
-    >= 0.999 (north-star gate); the delta cosine is printed and bounded."""
+@pytest.mark.parametrize("attn_type", ["hip_fp8_attn", "hip_fp8_attn_linear"])
+def test_block_with_fp8_attention_meets_the_block_gate(cuda, attn_type):
+    """Wan block with `self_attn_1_type = hip_fp8_attn` (and its exp-free variant) against the reference's
+    fp32 run: output cosine >= 0.999 (north-star gate); the delta cosine is printed and bounded."""
     from tests.util import case_inputs, load_golden
 
     rec = load_golden("wan1p3b_g3x30x52")
     c = case_inputs(rec)
-    cfg = {"num_layers": 1, "num_heads": c["heads"], "dim": c["dim"], "task": "t2v", "self_attn_1_type": "hip_fp8_attn"}
+    cfg = {"num_layers": 1, "num_heads": c["heads"], "dim": c["dim"], "task": "t2v", "self_attn_1_type": attn_type}
     W = L.WanTransformerWeights(cfg)
     W.load({k: v.to(cuda) for k, v in {**c["w"], **c["hw"]}.items()})
     inf = L.WanTransformerInfer(cfg)
@@ -121,5 +186,6 @@ def test_block_with_fp8_attention_meets_the_block_gate(cuda):
     rows = torch.from_numpy(rec["rows"]).long()
     ref = torch.from_numpy(rec["x_out"])
     c_out, c_delta = cos(out[rows], ref), cos(out[rows] - c["x"][rows], ref - c["x"][rows])
-    print(f"\nblock with fp8 self-attention (S={c['S']}): output cosine {c_out:.6f}, delta cosine {c_delta:.6f}")
+    print(f"\nblock with {attn_type} self-attention (S={c['S']}): output cosine {c_out:.6f}, delta cosine {c_delta:.6f}")
     assert c_out >= 0.999 and c_delta >= 0.99
+    assert hip.get_option("attn_fp8_p") == 0   # the linear plugin sets the option around its launch only

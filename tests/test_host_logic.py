@@ -48,7 +48,7 @@ def test_adopt_into_foreign_registries():
 
     added = registry_factory.adopt_into(Foreign)
     assert "hip-bf16" in Foreign.MM_WEIGHT_REGISTER and "hip_flash_attn" in Foreign.ATTN_WEIGHT_REGISTER
-    assert added["ATTN_WEIGHT_REGISTER"] == ["hip_flash_attn", "hip_fp8_attn", "hip_ulysses"]
+    assert added["ATTN_WEIGHT_REGISTER"] == ["hip_flash_attn", "hip_fp8_attn", "hip_fp8_attn_linear", "hip_ulysses"]
     assert registry_factory.adopt_into(Foreign) == {}  # idempotent
 
 
@@ -220,6 +220,9 @@ def test_options_roundtrip_and_reject_unknown_names():
         hip.set_option("no_such_option", 1)
     with pytest.raises(hip.Lx2vError, match="attn_qb"):
         hip.set_option("attn_qb", 7)
+    assert hip.get_option("attn_fp8_p") == 0          # exact exps unless asked otherwise
+    with pytest.raises(hip.Lx2vError, match="attn_fp8_p"):
+        hip.set_option("attn_fp8_p", 2)
 
 
 def test_static_scratch_entry_point_rejects_oversize_without_touching_the_gpu():

@@ -10,7 +10,12 @@ then do silently break results:
     which is when the first one has finished its passes), counted as a note when one MFMA lies
     between.  MFMAs the compiler emitted itself (builtins) are its own business: it knows their latency;
   * move data through the ring registers -- flagged for any compiler-generated instruction that
-    names a register at or above --ring-base.
+    names a register at or above --ring-base;
+  * touch the VGPR destination of an inline-asm LDS read before a wait: the read returns at once and
+    the data lands later; the kernels wait (s_waitcnt lgkmcnt, also inline asm) before THEIR use, but
+    a copy the compiler makes in between (to park the value in another register) takes what was in
+    the register before -- flagged for any compiler-generated instruction that names such a register
+    between the read and the next s_waitcnt with an lgkmcnt field.
 Exit status 1 when anything is flagged.  usage: check_mfma_hazards.py file.s [--kernel substring] [--ring-base 224]"""
 import re
 import sys
@@ -49,8 +54,21 @@ def check(path, kernel_filter, ring_base):
                 continue
             rows.append((t.split(";")[0].strip(), in_asm))
         pending = []  # [regs, mfmas_seen, text]
+        landing = []  # [regs, text] of asm LDS reads into VGPRs that no wait has covered yet
         notes = 0
         for t, from_asm in rows:
+            if t.startswith("s_waitcnt") and "lgkmcnt" in t:
+                landing = []
+            if not from_asm:
+                touched_l = regs(t, "v")
+                for q in landing:
+                    if touched_l & q[0]:
+                        print(f"{name}: '{t}' touches the destination of '{q[1]}' before any wait for it")
+                        bad += 1
+            elif t.startswith("ds_read") or t.startswith("ds_bpermute"):
+                d = regs(t.split(None, 1)[1].split(",")[0], "v")
+                if d:
+                    landing.append([d, t])
             if not from_asm:
                 if ring_base is not None and any(r >= ring_base for r in regs(t, "a")):
                     print(f"{name}: compiler-generated instruction touches the ring: {t}")

@@ -1,7 +1,7 @@
 #!/bin/bash
 # fp8 one-wave-per-SIMD attention kernel: timing ablations (results are wrong with any bit set).
 #   tools/f8w4_ablations.sh build 1 2 4 ...   (here: builds build/f8w4_abl<N>/liblx2v_hip.so)
-#   tools/f8w4_ablations.sh run 0 1 2 4 ...   (GPU box: kernel time of the attention launch per library; 0 = the product library, w8 = its 8-wave kernel)
+#   tools/f8w4_ablations.sh run 0 1 2 4 ...   (GPU box: kernel time of the attention launch per library; 0 = the product library, w8 = its 8-wave kernel, lin = its exp-free P)
 set -o pipefail
 cd "$(dirname "$0")/.."
 mode=$1; shift
@@ -23,8 +23,9 @@ for m in "$@"; do
   [ "$m" = 0 ] && lib=lightx2v_amd
   [ "$m" = w8 ] && { lib=lightx2v_amd; export LX2V_ATTN_FP8_KERNEL=w8; }
   [ "$m" = nosync ] && { lib=lightx2v_amd; export LX2V_ATTN_ROUND_SYNC=0; }
+  [ "$m" = lin ] && { lib=lightx2v_amd; export LX2V_ATTN_FP8_P=linear; }
   LD_LIBRARY_PATH=$lib timeout -s KILL 90 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/f8abl/m$m -o p -- ./build/kernel_harness selfattn8 75600 40 3 > gpurun_out/f8abl/m$m.log 2>&1 || { echo "mask $m: run failed"; tail -3 gpurun_out/f8abl/m$m.log; exit 1; }
-  unset LX2V_ATTN_ROUND_SYNC
+  unset LX2V_ATTN_ROUND_SYNC LX2V_ATTN_FP8_P
   f=$(find gpurun_out/f8abl/m$m -name "*counter_collection.csv" | head -1)
   t=$(find gpurun_out/f8abl/m$m -name "*kernel_trace.csv" | head -1)
   python3 - "$m" "$f" "$t" <<'PY'
