@@ -192,7 +192,25 @@ LX2V_DEVICE uint32_t cvt4_u8_op(float s0, float s1, float s2, float s3) {
                : F8_RING_CLOBBERS);
   return pk;
 }
-LX2V_DEVICE void or_op(uint32_t& acc, uint32_t v) { asm volatile("v_or_b32 %0, %0, %1" : "+v"(acc) : "v"(v) : F8_RING_CLOBBERS); }
+// The gap forms: one or two P dwords and their contribution to the or of the tile's codes, as ONE statement (between two
+// statements of which the second reads what the first wrote the compiler puts a wait state of its own).
+LX2V_DEVICE uint32_t cvt4_u8_or_op(uint32_t& acc, float s0, float s1, float s2, float s3) {
+  uint32_t pk;
+  asm volatile("v_cvt_pk_u8_f32 %0, %2, 0, 0\n\tv_cvt_pk_u8_f32 %0, %3, 1, %0\n\tv_cvt_pk_u8_f32 %0, %4, 2, %0\n\tv_cvt_pk_u8_f32 %0, %5, 3, %0\n\t"
+               "v_or_b32 %1, %1, %0"
+               : "=&v"(pk), "+v"(acc)
+               : "v"(s0), "v"(s1), "v"(s2), "v"(s3)
+               : F8_RING_CLOBBERS);
+  return pk;
+}
+LX2V_DEVICE void cvt8_u8_or_op(uint32_t& pa, uint32_t& pb, uint32_t& acc, float a0, float a1, float a2, float a3, float b0, float b1, float b2, float b3) {
+  asm volatile("v_cvt_pk_u8_f32 %0, %3, 0, 0\n\tv_cvt_pk_u8_f32 %1, %7, 0, 0\n\tv_cvt_pk_u8_f32 %0, %4, 1, %0\n\tv_cvt_pk_u8_f32 %1, %8, 1, %1\n\t"
+               "v_cvt_pk_u8_f32 %0, %5, 2, %0\n\tv_cvt_pk_u8_f32 %1, %9, 2, %1\n\tv_cvt_pk_u8_f32 %0, %6, 3, %0\n\tv_cvt_pk_u8_f32 %1, %10, 3, %1\n\t"
+               "v_or3_b32 %2, %2, %0, %1"
+               : "=&v"(pa), "=&v"(pb), "+v"(acc)
+               : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3)
+               : F8_RING_CLOBBERS);
+}
 // Row sums on the MFMA pipe: lsum (accumulator file) += SEL x P^T, SEL a constant 16 x 128 operand
 // whose rows 0-7 are ones on k-blocks 0 and 2 and rows 8-15 ones on k-blocks 1 and 3.  P is laid out
 // for the 32x32x64 B operand (lane = row mod 32, k-block = lane / 32), which this shape reads as
@@ -524,12 +542,17 @@ __global__ __launch_bounds__(F8_THREADS) void attn_fwd_fp8_w4_kernel(const Fp8At
         // row-sum MFMA follows a gap later, behind that gap's VALU work (right behind the gap's own MFMA
         // it would hold the wave until that one has left the pipe).
         if constexpr (LIN && !(F8W4_ABL & 1)) {
-          constexpr int D0 = G < 4 ? 2 * G : G < 12 ? G + 4 : -1, ND = G < 4 ? 2 : G < 12 ? 1 : 0;
-          static_for<0, ND>([&](auto ic) __attribute__((always_inline)) {
-            constexpr int D = D0 + decltype(ic)::value, dq = D >> 3, dkb = (D >> 2) & 1, dw = D & 3;
-            Pc[dq][D & 7] = (int)cvt4_u8_op(Sc[dkb][dq][4 * dw], Sc[dkb][dq][4 * dw + 1], Sc[dkb][dq][4 * dw + 2], Sc[dkb][dq][4 * dw + 3]);
-            or_op(orv, (uint32_t)Pc[dq][D & 7]);
-          });
+          if constexpr (G < 4) {  // dwords 2 G and 2 G + 1 of block 0: the same key block, adjacent score quads
+            constexpr int dkb = G >> 1, dw = 2 * (G & 1);
+            uint32_t pa, pb;
+            cvt8_u8_or_op(pa, pb, orv, Sc[dkb][0][4 * dw], Sc[dkb][0][4 * dw + 1], Sc[dkb][0][4 * dw + 2], Sc[dkb][0][4 * dw + 3],
+                          Sc[dkb][0][4 * dw + 4], Sc[dkb][0][4 * dw + 5], Sc[dkb][0][4 * dw + 6], Sc[dkb][0][4 * dw + 7]);
+            Pc[0][2 * G] = (int)pa;
+            Pc[0][2 * G + 1] = (int)pb;
+          } else if constexpr (G < 12) {
+            constexpr int D = G - 4, dkb = D >> 2, dw = D & 3;
+            Pc[1][D] = (int)cvt4_u8_or_op(orv, Sc[dkb][1][4 * dw], Sc[dkb][1][4 * dw + 1], Sc[dkb][1][4 * dw + 2], Sc[dkb][1][4 * dw + 3]);
+          }
           if constexpr (G == 5) mfma_rowsum(lsum[0], sel, Pc[0], unit);
           if constexpr (G == 12) mfma_rowsum(lsum[1], sel, Pc[1], unit);
         }
