@@ -120,6 +120,48 @@ def test_fp8_attention_with_linear_p(cuda, linear_p, sq, skv, H):
     assert cos(out, ref) >= cos(emu, ref) - 2e-4
 
 
+@pytest.mark.parametrize("sq,skv,H", [(5, 1, 1), (130, 33, 2), (64, 65, 1), (1, 700, 1), (1000, 512, 2)])
+def test_fp8_attention_with_linear_p_edge_shapes(cuda, linear_p, sq, skv, H):
+    """One key, ragged last tiles of one to 63 keys, a single query row, the cross-attention shape (the
+    kernel's short-sequence instance): against the fp32 softmax and against the exp formulation."""
+    q, k, v = _qkv(sq, skv, H, 40 + sq + skv)
+    out = hip.attn_fwd_fp8(q.to(cuda), k.to(cuda), v.to(cuda)).float().cpu()
+    hip.set_option("attn_fp8_p", 0)
+    exact = hip.attn_fwd_fp8(q.to(cuda), k.to(cuda), v.to(cuda)).float().cpu()
+    hip.set_option("attn_fp8_p", 1)
+    ref = R.sdpa(q.float(), k.float(), v.float())
+    print(f"\nlinear P, sq={sq} skv={skv} H={H}: cos vs fp32 {cos(out, ref):.6f} (exp formulation {cos(exact, ref):.6f}), cos between the two {cos(out, exact):.6f}")
+    assert torch.isfinite(out).all()
+    assert cos(out, ref) >= (0.9975 if skv > 1 else 0.9995)   # one key: P = 1 whatever the rule, what is left is the rounding of v
+    assert cos(out, exact) >= 0.998
+
+
+def test_fp8_attention_with_linear_p_degenerate_scores(cuda, linear_p):
+    """All scores equal (q = 0: every P is the code of 1.0 and a 64-key tile adds 64 to a row's sum, well below the
+    check's 2^8), and scores so far apart that one key carries a row alone."""
+    S, H = 300, 1
+    g = torch.Generator().manual_seed(3)
+    v = torch.randn(S, H, 128, generator=g).to(torch.bfloat16)
+    k = torch.randn(S, H, 128, generator=g).to(torch.bfloat16)
+    q0 = torch.zeros(S, H, 128, dtype=torch.bfloat16)
+    out = hip.attn_fwd_fp8(q0.to(cuda), k.to(cuda), v.to(cuda)).float().cpu()
+    ref = R.sdpa(q0.float(), k.float(), v.float())
+    assert torch.isfinite(out).all() and cos(out, ref) >= 0.999
+    q1 = (k.float() * 6.0).to(torch.bfloat16)   # row i scores key i with 6 |k_i|^2 / sqrt(128) ~ 68: a one-hot softmax
+    out = hip.attn_fwd_fp8(q1.to(cuda), k.to(cuda), v.to(cuda)).float().cpu()
+    ref = R.sdpa(q1.float(), k.float(), v.float())
+    print(f"\none-hot rows, linear P: cos vs fp32 {cos(out, ref):.6f}")
+    assert torch.isfinite(out).all() and cos(out, ref) >= 0.999
+
+
+def test_fp8_attention_static_entry_point_with_linear_p(cuda, linear_p):
+    """The entry point that allocates nothing launches the same kernels: same option, same bits."""
+    q, k, v = (t.to(cuda) for t in _qkv(300, 500, 2, 12))
+    a = hip.attn_fwd_fp8(q, k, v)
+    b = hip.attn_fwd_fp8_static(q, k, v, torch.empty_like(a))
+    assert torch.equal(a, b)
+
+
 def test_fp8_attention_with_linear_p_peaked_scores(cuda, linear_p):
     """Score spread of 6: later tiles exceed the running maximum by more than 2^8 for some rows, so the
     check on the row-sum increase fires and the rare path re-bases (and re-adds the tile's row sums)."""
