@@ -220,7 +220,7 @@ LX2V_DEVICE void mfma_rowsum(f32x4& lsum, const i32x8& sel, const i32x8& pf, int
   asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+a"(lsum) : "a"(sel), "v"(pf), "v"(unit) : F8_RING_CLOBBERS);
 }
 constexpr float kLinOne = 56.0f;       // code of P = 1
-constexpr float kLinMaxTileSum = 256.0f;  // a tile that adds less than this to a row's sum holds no P at or above 2^8 (e4m3 ends at 448)
+constexpr uint32_t kLinMaxTileSumBits = 0x43800000u;  // 256.0f: a tile that adds less than this to a row's sum holds no P at or above 2^8 (e4m3 ends at 448)
 
 template <bool SHORT_KV, bool LIN>
 __global__ __launch_bounds__(F8_THREADS) void attn_fwd_fp8_w4_kernel(const Fp8AttnParams p, const RoundSync rs) {
@@ -472,6 +472,8 @@ __global__ __launch_bounds__(F8_THREADS) void attn_fwd_fp8_w4_kernel(const Fp8At
     float ls[2] = {0.f, 0.f};
     uint32_t orv = 0;  // LIN: the P dwords of the tile or-ed together
     asm volatile("" : "+v"(orv));
+    float lnow[2] = {0.f, 0.f};  // LIN: the row sums with the tile added, and whether the tile broke e4m3's range (per lane)
+    uint32_t broke = 0;
     float e[2][4];  // exps of the dword of this gap / of the previous one
     if ((t + 1) * KVB > p.skv) mask_tile(Sc, t * KVB);  // wave-uniform: the last real tile when ragged, and the tile past the end
     int ksc_next[2] = {0, 0}, vsc_next = 0;
@@ -553,8 +555,22 @@ __global__ __launch_bounds__(F8_THREADS) void attn_fwd_fp8_w4_kernel(const Fp8At
             constexpr int D = G - 4, dkb = D >> 2, dw = D & 3;
             Pc[1][D] = (int)cvt4_u8_or_op(orv, Sc[dkb][1][4 * dw], Sc[dkb][1][4 * dw + 1], Sc[dkb][1][4 * dw + 2], Sc[dkb][1][4 * dw + 3]);
           }
-          if constexpr (G == 5) mfma_rowsum(lsum[0], sel, Pc[0], unit);
+          if constexpr (G == 5) mfma_rowsum(lsum[0], sel, Pc[0], unit);   // (gaps 4 / 13 instead: the same time)
           if constexpr (G == 12) mfma_rowsum(lsum[1], sel, Pc[1], unit);
+          // The overflow check of the tile, in a gap that has nothing else to do: what the tile added to each row's sum.
+          // The later row-sum MFMA was issued two gaps ago and two 16-pass MFMAs have entered the pipe behind it, each of
+          // which waits for its predecessor to leave it: no wait states needed.  A P at or above 2^8 -- e4m3 ends at 448,
+          // the code after it is NaN, saturated conversions read as negative numbers -- shows as an increase of at
+          // least 2^8, as a NaN, or as a code with the sign bit.  Only the vote and the branch are left for the period's end.
+          if constexpr (G == 14) {
+            asm volatile("" : "+a"(lsum[0]), "+a"(lsum[1]));
+            lnow[0] = lsum[0][0];
+            lnow[1] = lsum[1][0];
+            // (on the bit patterns: this file is compiled with "no NaNs", under which !(x < c) may become c <= x)
+            const uint32_t d0 = __float_as_uint(lnow[0] - lprev[0]) & 0x7fffffffu, d1 = __float_as_uint(lnow[1] - lprev[1]) & 0x7fffffffu;
+            broke = (d0 >= kLinMaxTileSumBits || d1 >= kLinMaxTileSumBits || (orv & 0x80808080u) != 0) ? 1u : 0u;
+            asm volatile("" : "+v"(broke), "+v"(lnow[0]), "+v"(lnow[1]));
+          }
         }
         // softmax share of gap G: exps of dword G, consumers of dword G - 1
         if constexpr (!LIN && !(F8W4_ABL & 1)) {
@@ -589,13 +605,8 @@ __global__ __launch_bounds__(F8_THREADS) void attn_fwd_fp8_w4_kernel(const Fp8At
     asm volatile("" : "+v"(Pc[0]), "+v"(Pc[1]), "+v"(ls[0]), "+v"(ls[1]));
     const bool first = t == 0;  // tile 0: m becomes its true row maximum
     if constexpr (LIN) {
-      // What the tile added to each row's sum (the row-sum MFMAs were issued three and ten gaps ago; the
-      // wait states cover the architectural minimum all the same).  A P at or above 2^8 -- e4m3 ends at
-      // 448, the code after it is NaN, saturated conversions read as negative numbers -- shows as an
-      // increase of at least 2^8, as a NaN, or as a code with the sign bit.
-      asm volatile("s_nop 7\n\ts_nop 3" : "+a"(lsum[0]), "+a"(lsum[1]));
-      const float l0 = lsum[0][0], l1 = lsum[1][0];
-      const bool over = __any(!(l0 - lprev[0] < kLinMaxTileSum) || !(l1 - lprev[1] < kLinMaxTileSum) || (orv & 0x80808080u) != 0);
+      const float l0 = lnow[0], l1 = lnow[1];
+      const bool over = __any(broke != 0);
       if (!(F8W4_ABL & 16) && __builtin_expect(first || over, 0)) {
         static_for<0, 2>([&](auto qbc) __attribute__((always_inline)) { fixup(qbc, Sc, Sn, Pc[decltype(qbc)::value], first, ls[decltype(qbc)::value]); });
       } else {

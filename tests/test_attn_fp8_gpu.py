@@ -154,6 +154,29 @@ def test_fp8_attention_with_linear_p_degenerate_scores(cuda, linear_p):
     assert torch.isfinite(out).all() and cos(out, ref) >= 0.999
 
 
+@pytest.mark.parametrize("jump", [8.875, 8.0, 9.5, 20.0])
+def test_fp8_attention_with_linear_p_catches_every_kind_of_overflow(cuda, linear_p, jump):
+    """One key of the second tile scores `jump` (in log2 units) above everything before it, with operands that the
+    quantisation keeps exactly: 8.875 lands on code 127 (e4m3's NaN), 8.0 on 120 (a finite 256: caught by the size of the
+    row-sum increase), 9.5 and 20 saturate into the codes with the sign bit.  The rare path must take all of them."""
+    S, H = 128, 1
+    q = torch.zeros(S, H, 128)
+    q[:, 0, 0] = 1.0
+    q[:, 0, 1] = 1.0
+    k = torch.zeros(S, H, 128)
+    hi, lo = (8.0, jump - 8.0) if jump < 16 else (16.0, jump - 16.0)
+    k[100, 0, 0], k[100, 0, 1] = hi, lo      # score = hi + lo = jump with scale * log2(e) = 1
+    g = torch.Generator().manual_seed(8)
+    v = torch.randn(S, H, 128, generator=g)
+    qb, kb, vb = (t.to(torch.bfloat16) for t in (q, k, v))
+    out = hip.attn_fwd_fp8(qb.to(cuda), kb.to(cuda), vb.to(cuda), scale=1.0 / math.log2(math.e)).float().cpu()
+    w = torch.exp2(torch.einsum("qhd,khd->hqk", qb.double(), kb.double()))
+    ref = torch.einsum("hqk,khd->qhd", w / w.sum(-1, keepdim=True), vb.double()).reshape(S, H * 128).float()
+    print(f"\njump {jump}: cos vs fp32 {cos(out, ref):.6f}")
+    assert torch.isfinite(out).all()
+    assert cos(out, ref) >= 0.998
+
+
 def test_fp8_attention_static_entry_point_with_linear_p(cuda, linear_p):
     """The entry point that allocates nothing launches the same kernels: same option, same bits."""
     q, k, v = (t.to(cuda) for t in _qkv(300, 500, 2, 12))

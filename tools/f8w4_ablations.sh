@@ -24,6 +24,7 @@ for m in "$@"; do
   [ "$m" = w8 ] && { lib=lightx2v_amd; export LX2V_ATTN_FP8_KERNEL=w8; }
   [ "$m" = nosync ] && { lib=lightx2v_amd; export LX2V_ATTN_ROUND_SYNC=0; }
   [ "$m" = lin ] && { lib=lightx2v_amd; export LX2V_ATTN_FP8_P=linear; }
+  case "$m" in lv*) export LX2V_ATTN_FP8_P=linear;; esac
   LD_LIBRARY_PATH=$lib timeout -s KILL 90 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/f8abl/m$m -o p -- ./build/kernel_harness selfattn8 75600 40 3 > gpurun_out/f8abl/m$m.log 2>&1 || { echo "mask $m: run failed"; tail -3 gpurun_out/f8abl/m$m.log; exit 1; }
   unset LX2V_ATTN_ROUND_SYNC LX2V_ATTN_FP8_P
   f=$(find gpurun_out/f8abl/m$m -name "*counter_collection.csv" | head -1)
