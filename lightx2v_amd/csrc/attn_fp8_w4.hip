@@ -617,8 +617,8 @@ __global__ __launch_bounds__(F8_THREADS) void attn_fwd_fp8_w4_kernel(const Fp8At
       if (!(F8W4_ABL & 16) && __builtin_expect(first || __any(!(fmaxf(ls[0], ls[1]) <= kMaxLaneSum)), 0)) {
         static_for<0, 2>([&](auto qbc) __attribute__((always_inline)) { fixup(qbc, Sc, Sn, Pc[decltype(qbc)::value], first, ls[decltype(qbc)::value]); });
       }
-      l_run[0] += ls[0];
-      l_run[1] += ls[1];
+      add_op(l_run[0], ls[0]);   // (single adds: the compiler's v_pk_add_f32 costs a lone wave more than two of them)
+      add_op(l_run[1], ls[1]);
     }
   };
 

@@ -409,11 +409,14 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
       lmax = fmaxf(lmax, ls[qb]);
     }
     const bool first = PAR == 0 && t == 0;  // half tile 0: m becomes its true row maximum
-    if (!(X16_ABL & 16) && __builtin_expect(first || __any(lmax > kRescaleSum), 0)) {
+    const int over = __any(lmax > kRescaleSum);  // (one branch for "first or over": with || the compiler tests `first` in a branch of its own)
+    if (!(X16_ABL & 16) && __builtin_expect((int)first | over, 0)) {
       static_for<0, NQB>([&](auto qbc) __attribute__((always_inline)) { fixup(qbc, Sc, Sn, Pc[decltype(qbc)::value], first, ls[decltype(qbc)::value]); });
     }
+    // (as single adds: left to itself the compiler pairs them into v_pk_add_f32, which costs a lone wave about 18 issue
+    // cycles where two v_add_f32 cost 8, and computes them on both sides of the branch above)
 #pragma unroll
-    for (int qb = 0; qb < NQB; ++qb) l_run[qb] += ls[qb];
+    for (int qb = 0; qb < NQB; ++qb) add_op(l_run[qb], ls[qb]);
   };
 
   // ---- prologue: Q fragments scaled and parked; DMA groups of tiles -4, -3, -2 (K0; K1, V0; K2,
