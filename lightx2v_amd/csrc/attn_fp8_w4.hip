@@ -614,7 +614,8 @@ __global__ __launch_bounds__(F8_THREADS) void attn_fwd_fp8_w4_kernel(const Fp8At
         lprev[1] = l1;
       }
     } else {
-      if (!(F8W4_ABL & 16) && __builtin_expect(first || __any(!(fmaxf(ls[0], ls[1]) <= kMaxLaneSum)), 0)) {
+      const int over = __any(!(fmaxf(ls[0], ls[1]) <= kMaxLaneSum));  // (one branch for "first or over")
+      if (!(F8W4_ABL & 16) && __builtin_expect((int)first | over, 0)) {
         static_for<0, 2>([&](auto qbc) __attribute__((always_inline)) { fixup(qbc, Sc, Sn, Pc[decltype(qbc)::value], first, ls[decltype(qbc)::value]); });
       }
       add_op(l_run[0], ls[0]);   // (single adds: the compiler's v_pk_add_f32 costs a lone wave more than two of them)
