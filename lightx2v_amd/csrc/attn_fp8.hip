@@ -95,43 +95,54 @@ __global__ __launch_bounds__(256) void mxq_rows_kernel(const uint16_t* __restric
   }
 }
 
-// V part of the tile blobs: thread = one channel d of one (tile, head); reads its 64 keys (each
-// key row is a coalesced 256-byte read over the block), quantises the two groups of 32 consecutive
-// keys and writes its 64-byte V^T row in slot order.
-__global__ __launch_bounds__(128) void mxq_v_kernel(const uint16_t* __restrict__ v, int64_t ldv, int tokens, int heads, uint8_t* __restrict__ out, int tiles) {
-  const int tile = blockIdx.x, head = blockIdx.y, d = threadIdx.x;
-  float val[64];
+// V part of the tile blobs: thread = two adjacent channels of one (tile, head); reads their 64 keys as dwords (each
+// key row is a coalesced 256-byte read over the block's 64 lanes), quantises the two groups of 32 consecutive keys per
+// channel and writes the two 64-byte V^T rows in slot order.
+__global__ __launch_bounds__(64) void mxq_v_kernel(const uint16_t* __restrict__ v, int64_t ldv, int tokens, int heads, uint8_t* __restrict__ out, int tiles) {
+  const int tile = blockIdx.x, head = blockIdx.y, d0 = 2 * threadIdx.x;
+  float val[2][64];
+  const bool dword_ok = (ldv & 1) == 0 && (reinterpret_cast<uintptr_t>(v) & 3) == 0;   // every row's channel pair is a dword
 #pragma unroll
   for (int key = 0; key < 64; ++key) {
     const int64_t tok = (int64_t)tile * KVB + key;
-    val[key] = tok < tokens ? __uint_as_float((uint32_t)v[tok * ldv + head * HD + d] << 16) : 0.f;
+    uint32_t pair = 0;
+    if (tok < tokens) {
+      const uint16_t* src = v + tok * ldv + head * HD + d0;
+      pair = dword_ok ? *reinterpret_cast<const uint32_t*>(src) : ((uint32_t)src[0] | ((uint32_t)src[1] << 16));
+    }
+    val[0][key] = __uint_as_float(pair << 16);
+    val[1][key] = __uint_as_float(pair & 0xffff0000u);
   }
   uint8_t* blob = out + ((int64_t)head * tiles + tile) * TILE_BLOB;
-  int e8[2];
-  float inv[2];
 #pragma unroll
-  for (int grp = 0; grp < 2; ++grp) {  // scale groups: keys 0-31 and 32-63 of the tile
-    float amax = 0.f;
+  for (int ch = 0; ch < 2; ++ch) {
+    const int d = d0 + ch;
+    int e8[2];
+    float inv[2];
 #pragma unroll
-    for (int key = 0; key < 32; ++key) amax = fmaxf(amax, fabsf(val[32 * grp + key]));
-    e8[grp] = e8m0_for(amax);
-    inv[grp] = inv_scale(e8[grp]);
-    blob[V_SCALE + (grp * 32 + (d & 31)) * 4 + (d >> 5)] = (uint8_t)e8[grp];
-  }
+    for (int grp = 0; grp < 2; ++grp) {  // scale groups: keys 0-31 and 32-63 of the tile
+      float amax = 0.f;
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {  // 16-slot chunk c of half h = keys 32 c + 8 (j >> 2) + 4 h + (j & 3), j = 0..15
-      float a[8], b[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        a[i] = val[32 * c + 8 * (i >> 2) + 4 * h + (i & 3)];
-        b[i] = val[32 * c + 8 * ((i + 8) >> 2) + 4 * h + (i & 3)];
-      }
-      const u32x2 lo = quant8(a, inv[c]), hi = quant8(b, inv[c]);
-      const int chunk = 2 * h + c;
-      *reinterpret_cast<u32x4*>(blob + V_DATA + d * 64 + ((chunk ^ ((d >> 2) & 3)) << 4)) = u32x4{lo[0], lo[1], hi[0], hi[1]};
+      for (int key = 0; key < 32; ++key) amax = fmaxf(amax, fabsf(val[ch][32 * grp + key]));
+      e8[grp] = e8m0_for(amax);
+      inv[grp] = inv_scale(e8[grp]);
+      blob[V_SCALE + (grp * 32 + (d & 31)) * 4 + (d >> 5)] = (uint8_t)e8[grp];
     }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {  // 16-slot chunk c of half h = keys 32 c + 8 (j >> 2) + 4 h + (j & 3), j = 0..15
+        float a[8], b[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          a[i] = val[ch][32 * c + 8 * (i >> 2) + 4 * h + (i & 3)];
+          b[i] = val[ch][32 * c + 8 * ((i + 8) >> 2) + 4 * h + (i & 3)];
+        }
+        const u32x2 lo = quant8(a, inv[c]), hi = quant8(b, inv[c]);
+        const int chunk = 2 * h + c;
+        *reinterpret_cast<u32x4*>(blob + V_DATA + d * 64 + ((chunk ^ ((d >> 2) & 3)) << 4)) = u32x4{lo[0], lo[1], hi[0], hi[1]};
+      }
+  }
 }
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -403,7 +414,7 @@ static int attn_fwd_fp8_on(const uint16_t* q, int64_t ldq, const uint16_t* k, in
   LX2V_REQUIRE((qthreads + 255) / 256 < (1LL << 31) && (kthreads + 255) / 256 < (1LL << 31), LX2V_EUNSUP, "attn_fwd_fp8: grid too large");
   hipLaunchKernelGGL(mxq_rows_kernel<false>, dim3((unsigned)((qthreads + 255) / 256)), dim3(256), 0, st, q, ldq, (int)sq, heads, scale * 1.4426950408889634f, q8, qs, 0);
   hipLaunchKernelGGL(mxq_rows_kernel<true>, dim3((unsigned)((kthreads + 255) / 256)), dim3(256), 0, st, k, ldk, (int)skv, heads, 1.0f, kv, nullptr, (int)tiles);
-  hipLaunchKernelGGL(mxq_v_kernel, dim3((unsigned)tiles, (unsigned)heads), dim3(128), 0, st, v, ldv, (int)skv, heads, kv, (int)tiles);
+  hipLaunchKernelGGL(mxq_v_kernel, dim3((unsigned)tiles, (unsigned)heads), dim3(64), 0, st, v, ldv, (int)skv, heads, kv, (int)tiles);
 
   Fp8AttnParams p;
   p.q8 = q8; p.qs = qs; p.kv = kv; p.out = out; p.ldo = ldo;
