@@ -409,8 +409,11 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
       lmax = fmaxf(lmax, ls[qb]);
     }
     const bool first = PAR == 0 && t == 0;  // half tile 0: m becomes its true row maximum
-    const int over = __any(lmax > kRescaleSum);  // (one branch for "first or over": with || the compiler tests `first` in a branch of its own)
-    if (!(X16_ABL & 16) && __builtin_expect((int)first | over, 0)) {
+    // (half tile 0 takes the rare path through the threshold -- a scalar select made long before -- so that the period ends in one
+    // compare and one branch: with `first || over` the compiler tests `first` in a branch of its own, with `first | over` in
+    // five scalar instructions behind the compare)
+    const float thr = first ? -1.0f : kRescaleSum;
+    if (!(X16_ABL & 16) && __builtin_expect(__any(lmax > thr), 0)) {
       static_for<0, NQB>([&](auto qbc) __attribute__((always_inline)) { fixup(qbc, Sc, Sn, Pc[decltype(qbc)::value], first, ls[decltype(qbc)::value]); });
     }
     // (as single adds: left to itself the compiler pairs them into v_pk_add_f32, which costs a lone wave about 18 issue
