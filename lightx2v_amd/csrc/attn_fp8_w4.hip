@@ -475,7 +475,7 @@ __global__ __launch_bounds__(F8_THREADS) void attn_fwd_fp8_w4_kernel(const Fp8At
     float lnow[2] = {0.f, 0.f};  // LIN: the row sums with the tile added, and whether the tile broke e4m3's range (per lane)
     uint32_t broke = 0;
     float e[2][4];  // exps of the dword of this gap / of the previous one
-    if ((t + 1) * KVB > p.skv) mask_tile(Sc, t * KVB);  // wave-uniform: the last real tile when ragged, and the tile past the end
+    if (__builtin_expect((t + 1) * KVB > p.skv, 0)) mask_tile(Sc, t * KVB);  // wave-uniform: the last real tile when ragged, and the tile past the end (kept out of the fall-through path)
     int ksc_next[2] = {0, 0}, vsc_next = 0;
     // tiles staged in this period (past the last tile of the image: the last one again, never used)
     const uint32_t k_soff = (uint32_t)min(t + 7, p.tiles - 1) * TILE_BLOB, v_soff = (uint32_t)min(t + 5, p.tiles - 1) * TILE_BLOB;

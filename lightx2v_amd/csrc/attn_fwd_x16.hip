@@ -275,7 +275,7 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
     for (int qb = 0; qb < NQB; ++qb) ls[qb] = 0.f;
     float ea[NPAIR], eb[NPAIR];  // exps of pair p = (qb = p >> 2, j = p & 3): scores [j >> 1][qb][2 (j & 1)], + 1
     const int key0 = t * KVB + 32 * PAR;
-    if (key0 + 32 > p.skv) mask_half(Sc, key0);  // wave-uniform: only the last real half tile and the zero tiles
+    if (__builtin_expect(key0 + 32 > p.skv, 0)) mask_half(Sc, key0);  // wave-uniform: only the last real half tile and the zero tiles (kept out of the fall-through path)
     // DMA of this period: odd periods bring K(t+4) into the slot K(t) just left, even periods
     // V(t+2) into the slot V(t-2) left at the previous barrier; four pieces each, on even steps:
     // 0, 4, 8, 10 of the even periods (before their barrier, so that the count there is the same
