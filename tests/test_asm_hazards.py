@@ -51,6 +51,14 @@ def test_checker_flags_compiler_traffic_through_the_ring(tmp_path):
     assert _run(tmp_path, between="\t;;#ASMSTART\n\tds_read_b128 a[248:251], v1\n\t;;#ASMEND", ring_base=224) == 0
 
 
+def test_checker_flags_an_lds_read_destination_touched_before_a_wait(tmp_path):
+    read = "\t;;#ASMSTART\n\tds_read_b32 v11, v10 offset:0x6600\n\t;;#ASMEND\n"
+    wait = "\t;;#ASMSTART\n\ts_waitcnt lgkmcnt(4)\n\t;;#ASMEND\n"
+    assert _run(tmp_path, between=read + "\tv_accvgpr_write_b32 a221, v11") == 1            # parked before the data has landed
+    assert _run(tmp_path, between=read + wait + "\tv_accvgpr_write_b32 a221, v11") == 0     # behind a wait
+    assert _run(tmp_path, between=read + "\tv_mov_b32_e32 v12, v13") == 0                   # other registers
+
+
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc")
 def test_kernels_with_inline_asm_mfmas_are_clean():
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "lightx2v_amd", "csrc"), "-j4", "asmcheck"], capture_output=True, text=True, timeout=1500)
