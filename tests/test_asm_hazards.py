@@ -56,7 +56,7 @@ def test_checker_flags_an_lds_read_destination_touched_before_a_wait(tmp_path):
     wait = "\t;;#ASMSTART\n\ts_waitcnt lgkmcnt(4)\n\t;;#ASMEND\n"
     assert _run(tmp_path, between=read + "\tv_accvgpr_write_b32 a221, v11") == 1            # parked before the data has landed
     assert _run(tmp_path, between=read + wait + "\tv_accvgpr_write_b32 a221, v11") == 0     # behind a wait
-    assert _run(tmp_path, between=read + "\tv_mov_b32_e32 v12, v13") == 0                   # other registers
+    assert _run(tmp_path, between=read + "\tv_mov_b32_e32 v20, v21") == 0                   # other registers
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc")
