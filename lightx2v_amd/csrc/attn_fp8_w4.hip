@@ -192,14 +192,14 @@ LX2V_DEVICE uint32_t cvt4_u8_op(float s0, float s1, float s2, float s3) {
                : F8_RING_CLOBBERS);
   return pk;
 }
-// The gap forms: one or two P dwords and their contribution to the or of the tile's codes, as ONE statement (between two
+// The gap forms: one or two P dwords and the or of the tile's codes taken over two dwords at a time, as ONE statement (between two
 // statements of which the second reads what the first wrote the compiler puts a wait state of its own).
-LX2V_DEVICE uint32_t cvt4_u8_or_op(uint32_t& acc, float s0, float s1, float s2, float s3) {
+LX2V_DEVICE uint32_t cvt4_u8_or3_op(uint32_t& acc, uint32_t other, float s0, float s1, float s2, float s3) {
   uint32_t pk;
-  asm volatile("v_cvt_pk_u8_f32 %0, %2, 0, 0\n\tv_cvt_pk_u8_f32 %0, %3, 1, %0\n\tv_cvt_pk_u8_f32 %0, %4, 2, %0\n\tv_cvt_pk_u8_f32 %0, %5, 3, %0\n\t"
-               "v_or_b32 %1, %1, %0"
+  asm volatile("v_cvt_pk_u8_f32 %0, %3, 0, 0\n\tv_cvt_pk_u8_f32 %0, %4, 1, %0\n\tv_cvt_pk_u8_f32 %0, %5, 2, %0\n\tv_cvt_pk_u8_f32 %0, %6, 3, %0\n\t"
+               "v_or3_b32 %1, %1, %0, %2"
                : "=&v"(pk), "+v"(acc)
-               : "v"(s0), "v"(s1), "v"(s2), "v"(s3)
+               : "v"(other), "v"(s0), "v"(s1), "v"(s2), "v"(s3)
                : F8_RING_CLOBBERS);
   return pk;
 }
@@ -551,9 +551,10 @@ __global__ __launch_bounds__(F8_THREADS) void attn_fwd_fp8_w4_kernel(const Fp8At
                           Sc[dkb][0][4 * dw + 4], Sc[dkb][0][4 * dw + 5], Sc[dkb][0][4 * dw + 6], Sc[dkb][0][4 * dw + 7]);
             Pc[0][2 * G] = (int)pa;
             Pc[0][2 * G + 1] = (int)pb;
-          } else if constexpr (G < 12) {
+          } else if constexpr (G < 12) {  // one dword of block 1 per gap; the or takes two dwords at a time, in every second gap
             constexpr int D = G - 4, dkb = D >> 2, dw = D & 3;
-            Pc[1][D] = (int)cvt4_u8_or_op(orv, Sc[dkb][1][4 * dw], Sc[dkb][1][4 * dw + 1], Sc[dkb][1][4 * dw + 2], Sc[dkb][1][4 * dw + 3]);
+            if constexpr ((D & 1) == 0) Pc[1][D] = (int)cvt4_u8_op(Sc[dkb][1][4 * dw], Sc[dkb][1][4 * dw + 1], Sc[dkb][1][4 * dw + 2], Sc[dkb][1][4 * dw + 3]);
+            else Pc[1][D] = (int)cvt4_u8_or3_op(orv, (uint32_t)Pc[1][D - 1], Sc[dkb][1][4 * dw], Sc[dkb][1][4 * dw + 1], Sc[dkb][1][4 * dw + 2], Sc[dkb][1][4 * dw + 3]);
           }
           if constexpr (G == 5) mfma_rowsum(lsum[0], sel, Pc[0], unit);   // (gaps 4 / 13 instead: the same time)
           if constexpr (G == 12) mfma_rowsum(lsum[1], sel, Pc[1], unit);
