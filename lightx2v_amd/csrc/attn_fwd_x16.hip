@@ -402,17 +402,17 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
       ls[NQB - 1] += ea[NPAIR - 1] + eb[NPAIR - 1];
       Pc[NQB - 1][3] = pack2(ea[NPAIR - 1], eb[NPAIR - 1]);
     }
-    float lmax = 0.f;
+    float lmax = 0.f;   // (the sums are positive: the first one needs no max with it)
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
       asm volatile("" : "+v"(Pc[qb]), "+v"(ls[qb]));
-      lmax = fmaxf(lmax, ls[qb]);
+      lmax = qb == 0 ? ls[0] : fmaxf(lmax, ls[qb]);
     }
     const bool first = PAR == 0 && t == 0;  // half tile 0: m becomes its true row maximum
     // (half tile 0 takes the rare path through the threshold -- a scalar select made long before -- so that the period ends in one
     // compare and one branch: with `first || over` the compiler tests `first` in a branch of its own, with `first | over` in
     // five scalar instructions behind the compare)
-    const float thr = first ? -1.0f : kRescaleSum;
+    const float thr = __builtin_bit_cast(float, first ? (int)0xbf800000 : __builtin_bit_cast(int, kRescaleSum));  // (selected as an integer: a scalar select, no v_cndmask)
     if (!(X16_ABL & 16) && __builtin_expect(__any(lmax > thr), 0)) {
       static_for<0, NQB>([&](auto qbc) __attribute__((always_inline)) { fixup(qbc, Sc, Sn, Pc[decltype(qbc)::value], first, ls[decltype(qbc)::value]); });
     }
