@@ -1,6 +1,7 @@
 #!/bin/bash
 # fp8 one-wave-per-SIMD attention kernel: timing ablations (results are wrong with any bit set).
 #   tools/f8w4_ablations.sh build 1 2 4 ...   (here: builds build/f8w4_abl<N>/liblx2v_hip.so)
+#   (a library built by hand into build/f8w4_abllv<N> is run with the exp-free P: tools/f8w4_ablations.sh run lv<N>)
 #   tools/f8w4_ablations.sh run 0 1 2 4 ...   (GPU box: kernel time of the attention launch per library; 0 = the product library, w8 = its 8-wave kernel, lin = its exp-free P)
 set -o pipefail
 cd "$(dirname "$0")/.."
