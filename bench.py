@@ -265,12 +265,40 @@ def cpu_baseline(D, H, F, full_S, layers, threads):
     sample_flops = sum(block_flops(S, D, H, F))
     rate = sample_flops / dt  # FLOP/s on this host
     full_flops = sum(block_flops(full_S, D, H, F)) * layers * 2
-    return {
+    out = {
         "value": full_flops / rate, "unit": "s/denoise-step", "cores": threads, "kind": "port", "cpu_model": cpu_model_name(),
-        "runs_s": [round(t, 3) for t in times],
+        "runs_s": [round(t, 3) for t in times], "extrapolated": True,
         "sample": f"one fp32 oracle block at S={S} tokens ({grid[0]}x{grid[1]}x{grid[2]}), D={D}: 1 warm-up + 3 timed runs, median {dt:.2f} s = {rate / 1e12:.3f} TFLOP/s on {threads} threads; "
-                  f"extrapolated by algorithmic FLOPs to {layers} blocks x 2 CFG passes at S={full_S}",
+                  f"EXTRAPOLATED by algorithmic FLOPs to {layers} blocks x 2 CFG passes at S={full_S}",
     }
+    if (D, H, F, full_S) == (1536, 12, 8960, 32760):
+        # BASELINE configuration 1 as it stands: one fp32 block of the 1.3B model at all 32 760 tokens, timed, nothing extrapolated
+        out.update(cpu_c1_block(threads))
+    return out
+
+
+def cpu_c1_block(threads):
+    """BASELINE.json configs[0]: one Wan2.1-T2V-1.3B block forward at 480x832x81f (32 760 tokens), fp32,
+    torch_sdpa attention, random-init weights, on the host cores: 1 warm-up + 3 timed runs."""
+    from oracle import wan_block_ref as R
+
+    torch.set_num_threads(threads)
+    D, H, F, grid = 1536, 12, 8960, GRIDS["480p"]
+    S = grid[0] * grid[1] * grid[2]
+    w = R.make_block_weights(D, F, seed=0)
+    x, context, embed0, _ = R.make_inputs(S, D, TEXT_LEN, seed=0)
+    cs = R.build_cos_sin(grid, D // H)
+    times = []
+    with torch.no_grad():
+        for run in range(4):
+            t0 = time.time()
+            R.block_forward(x, embed0, context, w, cs, H)
+            if run > 0:
+                times.append(time.time() - t0)
+    med = sorted(times)[1]
+    return {"c1_block_s": med, "c1_runs_s": [round(t, 3) for t in times],
+            "c1_sample": f"BASELINE config 1 unscaled: one fp32 oracle block, Wan2.1-T2V-1.3B dims, S={S}: 1 warm-up + 3 timed runs, median {med:.2f} s = "
+                         f"{sum(block_flops(S, D, H, F)) / med / 1e12:.3f} TFLOP/s on {threads} threads"}
 
 
 def attn_peak(args):
@@ -290,7 +318,12 @@ def arithmetic_label(args):
     return f"{lin} + {att}", " (" + ", ".join(x for x in (f"{args.linear} Linears" if args.linear != "bf16" else "", {"bf16": "", "fp8": "fp8 attention", "fp8-linear": "fp8 attention with exp-free P"}[args.attn]) if x) + ")"
 
 
-def run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu):
+def emulation_note(args, cfg_p, seq_p):
+    return (f" [--as-rank-of: single-GPU emulation of ONE rank of a cfg_p{cfg_p} x seq_p{seq_p} grid, exchanges replaced by device copies of the rank's own data; "
+            "compute-only prediction, not a scaling measurement]") if args.as_rank_of else ""
+
+
+def run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu, emulate=None):
     """HunyuanVideo-1.5, 4-step distilled schedule, no CFG: one step = scheduler.step_pre ->
     HunyuanVideo15Model.infer (pre-infer with the token refiner, all double-stream blocks, final
     layer, unpatchify) -> scheduler.step_post, on synthetic latents and encoder outputs."""
@@ -305,12 +338,16 @@ def run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu):
     grid = HY_GRIDS[args.res]
     S = grid[0] * grid[1] * grid[2]
     if cfg_p != 1:
-        seq_p, cfg_p = world, 1  # the distilled model runs without CFG: every rank joins the sequence group
+        seq_p, cfg_p = (world if emulate is None else cfg_p * seq_p), 1  # the distilled model runs without CFG: every rank joins the sequence group
     if H % seq_p != 0:
         raise SystemExit(f"heads_num={H} not divisible by seq_p={seq_p}")
     seq_group = None
     if world > 1 or args.sp1:
         _, _, seq_group, _ = ulysses.make_groups(1, seq_p)
+    if emulate is not None and seq_p > 1:
+        from lightx2v_amd import comm
+
+        seq_group = comm.EmulatedGroup(seq_p)
     C, TEXT_DIM, TXT_TOKENS, BYT5_TOKENS, VIS_TOKENS = 32, 3584, 1000, 256, 729
     cfg = {"mm_double_blocks_depth": layers, "heads_num": H, "hidden_size": D, "task": "t2v", "patch_size": (1, 1, 1), "out_channels": C,
            "dit_quant_scheme": {"bf16": "hip-bf16", "fp8": "hip-fp8", "int8": "hip-int8"}[args.linear],
@@ -419,13 +456,13 @@ def run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu):
     extra = {} if classes is None else classes.summary(args.steps, s_per_step * 1e3, sum(t.total_ms() for t in timers) / args.steps)
     return {
         **extra,
-        "metric": f"s/denoise-step {args.model} {args.res}{frames}f" + arithmetic_label(args)[1],
+        "metric": f"s/denoise-step {args.model} {args.res}{frames}f" + arithmetic_label(args)[1] + (f" (one rank of {cfg_p}x{seq_p}, emulated)" if args.as_rank_of else ""),
         "value": s_per_step, "unit": "s/denoise-step", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": s_per_step * 1e3, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
         "dtype": arithmetic_label(args)[0],
         "data": "synthetic latents, text / glyph / image-encoder features and masks, random-init weights of the named architecture"
                 + ("" if (backend == "nccl" and not share_gpu) else f" [REHEARSAL: backend={backend} share_gpu={share_gpu}, not a measurement]")
-                + (" [--sp1: sequence-parallel code path on an RCCL group of one rank]" if args.sp1 else ""),
+                + (" [--sp1: sequence-parallel code path on an RCCL group of one rank]" if args.sp1 else "") + emulation_note(args, cfg_p, seq_p),
         "config": {"workload": f"{args.model} {args.res} x{frames}f: {S} image + {HY_TEXT_LEN} text tokens, full denoise step (pre-infer with token refiner, {layers} double-stream blocks + final layer, unpatchify, distilled-schedule update), no CFG",
                    "parallelism": f"seq_p{seq_p} (ulysses)", "tokens": S, "dim": D, "heads": H, "ffn_dim": F, "layers": layers},
         "step_tflops": step_flops / 1e12, "achieved_tflops_per_gpu": step_flops / s_per_step / 1e12 / world,
@@ -460,7 +497,27 @@ def main():
                     help="one GPU only: run the sequence-parallel code path on an RCCL group of ONE rank (pack kernel, chunked attention, "
                          "asynchronous all-to-alls that move the rank's own data, segmented output projection, final all_gather); "
                          "prices what the N > 1 path costs besides the links")
+    ap.add_argument("--as-rank-of", default=None, metavar="CFGxSEQ",
+                    help="one GPU only: run what ONE rank of a cfg_p x seq_p grid computes (one CFG branch when cfg_p = 2, token-wise work on S/seq_p rows, "
+                         "attention on H/seq_p heads over all S rows in the exchange's real head chunks, segmented output projection); the exchanges are device "
+                         "copies of the rank's own data.  A single-GPU emulation that predicts the layout's compute-only s/step -- not a scaling measurement")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly (`python bench.py --gpus N`): become the launcher.  Nothing has touched the GPU in
+        # this process; the ranks are children of torch.distributed.run, rank 0's JSON line goes to our
+        # stdout through the inherited descriptor, and the launcher's exit status is ours.
+        import socket
+        import subprocess
+
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        raise SystemExit(subprocess.call(cmd))
 
     # stdout carries the one JSON line and nothing else: libraries that print to file descriptor 1 (RCCL's
     # version banner at communicator creation) are sent to stderr for the whole run
@@ -502,12 +559,22 @@ def main():
             comm.set_transport(comm.HostStagedTransport())
     cfg_p, seq_p = default_layout(world) if args.layout is None else tuple(int(v) for v in args.layout.lower().split("x"))
     assert cfg_p * seq_p == world and cfg_p in (1, 2)
+    emulate = None
+    if args.as_rank_of:
+        if world != 1 or args.sp1:
+            raise SystemExit("--as-rank-of is a one-GPU run (and excludes --sp1)")
+        from lightx2v_amd import comm
+
+        cfg_p, seq_p = (int(v) for v in args.as_rank_of.lower().split("x"))
+        assert cfg_p in (1, 2) and seq_p >= 1
+        comm.set_transport(comm.EmulatedPeersTransport())
+        emulate = (comm.EmulatedGroup(cfg_p) if cfg_p > 1 else None, comm.EmulatedGroup(seq_p) if seq_p > 1 else None)
 
     import lightx2v_amd as L
     from lightx2v_amd import ulysses
 
     if args.model in HY_MODELS:
-        line = run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu)
+        line = run_hunyuan(args, dev, world, rank, cfg_p, seq_p, backend, share_gpu, emulate)
         if rank == 0:
             print(json.dumps(line), file=json_out, flush=True)
         if world > 1 or args.sp1:
@@ -527,6 +594,8 @@ def main():
     seq_group = cfg_group = None
     if world > 1 or args.sp1:
         cfg_idx, seq_idx, seq_group, cfg_group = ulysses.make_groups(cfg_p, seq_p)
+    if emulate is not None:
+        cfg_group, seq_group = emulate
     cfg = {"num_layers": layers, "num_heads": H, "dim": D, "ffn_dim": F, "task": "t2v", "model_cls": "wan2.1",
            "in_dim": LATENT_CHANNELS, "out_dim": LATENT_CHANNELS, "freq_dim": 256, "infer_steps": 50, "sample_shift": 5.0,
            "sample_guide_scale": GUIDE_SCALE, "enable_cfg": True, "run_device": "cuda",
@@ -624,12 +693,12 @@ def main():
     exposed_ms = ulysses.COMM_TIMER.total_ms() / args.steps if (world > 1 or args.sp1) else 0.0
     if rank == 0:
         line = {
-            "metric": "s/denoise-step Wan2.1-T2V-14B 720p81f" if (args.model, args.res, args.linear, args.attn, args.residual) == ("wan2.1-t2v-14b", "720p", "bf16", "bf16", "bf16") else f"s/denoise-step {args.model} {args.res}81f" + arithmetic_label(args)[1],
+            "metric": "s/denoise-step Wan2.1-T2V-14B 720p81f" if (args.model, args.res, args.linear, args.attn, args.residual, args.as_rank_of) == ("wan2.1-t2v-14b", "720p", "bf16", "bf16", "bf16", None) else f"s/denoise-step {args.model} {args.res}81f" + arithmetic_label(args)[1] + (f" (one rank of {cfg_p}x{seq_p}, emulated)" if args.as_rank_of else ""),
             "value": s_per_step, "unit": "s/denoise-step", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": s_per_step * 1e3, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
             "dtype": arithmetic_label(args)[0], "data": "synthetic latents and text features, random-init weights of the named architecture"
                     + ("" if (backend == "nccl" and not share_gpu) else f" [REHEARSAL: backend={backend} share_gpu={share_gpu}, not a measurement]")
-                + (" [--sp1: sequence-parallel code path on an RCCL group of one rank]" if args.sp1 else ""),
+                + (" [--sp1: sequence-parallel code path on an RCCL group of one rank]" if args.sp1 else "") + emulation_note(args, cfg_p, seq_p),
             "config": {"workload": f"{args.model} {args.res} x81f: {S} tokens, full denoise step (pre-infer, {layers} blocks + head, unpatchify) x 2 CFG forwards + CFG combine + UniPC update, text len {TEXT_LEN}"
                                    + (f"; two resident experts, switch at t = {MOE_BOUNDARY} (experts of the timed steps: {picks[args.warmup:]}), {MOE_COND_CHANNELS} conditioning channels" if moe else "")
                                    + (f"; {CLIP_TOKENS} CLIP image tokens (img_emb MLP + second cross-attention per block), {MOE_COND_CHANNELS} conditioning channels" if i2v_clip else ""),
@@ -647,7 +716,7 @@ def main():
         }
         if classes is not None:
             line.update(classes.summary(args.steps, s_per_step * 1e3, sum(t.total_ms() for t in timers) / args.steps))
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.as_rank_of:
             threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
             line["cpu_baseline"] = cpu_baseline(D, H, F, S, layers, threads)
         print(json.dumps(line), file=json_out, flush=True)

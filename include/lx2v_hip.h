@@ -287,7 +287,11 @@ int lx2v_attn_fwd_fp8(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t
  * with LX2V_EUNSUP (e.g. 12 heads x 4 680 tokens need 22.6 MB; use lx2v_attn_fwd_fp8 beyond).
  * Calls no allocating routine.  All calls on one GPU share that GPU's array: calls that overlap on
  * one GPU (two streams, two threads) race; calls on one stream are ordered.  Nothing in the array
- * has to start at zero (the pre-pass of a call writes every byte its kernels read). */
+ * has to start at zero (the pre-pass of a call writes every byte its kernels read).
+ * Under stream capture: the FIRST call on a device resolves that device's copy of the array
+ * (hipGetSymbolAddress), so make one call per device outside capture before capturing one; a
+ * captured call leaves the long-sequence round alignment off (a replay cannot advance the host's
+ * view of the alignment counters), which changes no result. */
 #define LX2V_ATTN_FP8_STATIC_BYTES (32 << 20)
 int64_t lx2v_attn_fp8_static_bytes(void);
 int lx2v_attn_fwd_fp8_static(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk,

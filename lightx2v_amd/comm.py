@@ -26,13 +26,34 @@ import torch.distributed as dist
 RCCL_MAX_PEER_BYTES = 1 << 30
 
 
+class EmulatedGroup:
+    """Stand-in for a process group of `size` ranks of which this process plays rank `rank`, with no
+    peers behind it: `EmulatedPeersTransport` answers its collectives from the rank's own data.  A
+    single GPU then runs exactly the kernels one rank of such a group runs (token-wise work on S/N
+    rows, attention on H/N heads over all S rows, segmented output projection) -- a way to time one
+    rank's compute, never a way to produce results."""
+
+    def __init__(self, size: int, rank: int = 0):
+        if not 0 <= rank < size:
+            raise ValueError(f"EmulatedGroup: rank {rank} outside a group of {size}")
+        self.size, self.rank = size, rank
+
+
+def group_size(group) -> int:
+    return group.size if isinstance(group, EmulatedGroup) else dist.get_world_size(group)
+
+
+def group_rank(group) -> int:
+    return group.rank if isinstance(group, EmulatedGroup) else dist.get_rank(group)
+
+
 class DistTransport:
     """torch.distributed, unchanged (plus a refusal of payloads RCCL is known to truncate)."""
 
     name = "torch.distributed"
 
     def all_to_all_single(self, output: torch.Tensor, input: torch.Tensor, group=None, async_op: bool = False):
-        per_peer = input.numel() * input.element_size() // max(1, dist.get_world_size(group))
+        per_peer = input.numel() * input.element_size() // max(1, group_size(group))
         if per_peer > RCCL_MAX_PEER_BYTES and input.is_cuda:
             raise ValueError(f"all_to_all_single: {per_peer / 2**20:.0f} MiB per peer; RCCL moves payloads above 1024 MiB only in part -- split the exchange "
                              "(the Ulysses exchange does: LX2V_ULYSSES_MAX_PEER_MB)")
@@ -89,6 +110,36 @@ class HostStagedTransport(DistTransport):
             return staged
         staged.wait()
         return None
+
+
+class _DoneWork:
+    def wait(self):
+        return True
+
+
+class EmulatedPeersTransport(DistTransport):
+    """Collectives of an `EmulatedGroup`: every peer is assumed to hold what this rank holds, so an
+    all-to-all is a device copy of the send buffer into the receive buffer (slot j keeps this rank's
+    slot j: distinct, realistically distributed values in every row) and an all_gather fills every
+    output with the input.  The copies run on the current stream; nothing is overlapped and no link
+    is involved, which is the point: what remains is one rank's compute."""
+
+    name = "emulated peers (one rank's compute only)"
+
+    def all_to_all_single(self, output, input, group=None, async_op=False):
+        if not isinstance(group, EmulatedGroup):
+            raise ValueError("EmulatedPeersTransport serves EmulatedGroup groups only")
+        if output.numel() != input.numel():
+            raise ValueError("emulated all_to_all_single: equal splits only")
+        output.view(-1).copy_(input.reshape(-1))
+        return _DoneWork() if async_op else None
+
+    def all_gather(self, outputs, input, group=None, async_op=False):
+        if not isinstance(group, EmulatedGroup):
+            raise ValueError("EmulatedPeersTransport serves EmulatedGroup groups only")
+        for o in outputs:
+            o.copy_(input)
+        return _DoneWork() if async_op else None
 
 
 _transport: DistTransport = DistTransport()

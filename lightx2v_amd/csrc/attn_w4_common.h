@@ -95,7 +95,11 @@ int launch_with_rounds(KS kshort, KL klong, int threads, const P& p, int64_t kv_
   static RoundHost host[64];
   RoundHost* h = nullptr;
   unsigned slot = 0;
-  if (lx2v_options().attn_round_sync != 0 && kv_bytes_per_head > (8 << 20)) {
+  // A launch recorded into a graph would replay with the counter values of its capture baked in while the
+  // device counters move on with every replay: alignment is left off under capture (it is a locality hint only).
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  if (st != nullptr && hipStreamIsCapturing(st, &capturing) != hipSuccess) { (void)hipGetLastError(); capturing = hipStreamCaptureStatusNone; }
+  if (lx2v_options().attn_round_sync != 0 && kv_bytes_per_head > (8 << 20) && capturing == hipStreamCaptureStatusNone) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { lx2v_set_error("%s: hipGetDevice failed", what); return LX2V_EHIP; }
     std::lock_guard<std::mutex> lock(mu);

@@ -330,7 +330,7 @@ class HunyuanVideo15Scheduler:
             rope_dim_list = [head_dim // 3] * 3
         table = build_hunyuan_rope_table(rope_sizes, head_dim, rope_dim_list, self.config.get("rope_theta", 256.0), device=self.device)
         if self.seq_p_group is not None:
-            world, rank = dist.get_world_size(self.seq_p_group), dist.get_rank(self.seq_p_group)
+            world, rank = comm.group_size(self.seq_p_group), comm.group_rank(self.seq_p_group)
             pad = (world - (table.shape[0] % world)) % world
             if pad > 0:
                 table = torch.nn.functional.pad(table, (0, 0, 0, pad))
@@ -404,8 +404,8 @@ class HunyuanVideo15Model:
         sch = self.scheduler
         if self.config.get("enable_cfg", False):
             if self.cfg_p_group is not None:
-                assert dist.get_world_size(self.cfg_p_group) == 2, "cfg_p_world_size must be equal to 2"
-                mine = self._infer_cond_uncond(inputs, infer_condition=dist.get_rank(self.cfg_p_group) == 0).contiguous()
+                assert comm.group_size(self.cfg_p_group) == 2, "cfg_p_world_size must be equal to 2"
+                mine = self._infer_cond_uncond(inputs, infer_condition=comm.group_rank(self.cfg_p_group) == 0).contiguous()
                 parts = [torch.zeros_like(mine) for _ in range(2)]
                 comm.transport().all_gather(parts, mine, group=self.cfg_p_group)
                 cond, uncond = parts
@@ -429,7 +429,7 @@ class HunyuanVideo15Model:
 
     def _seq_parallel_pre_process(self, pre_infer_out):
         img = pre_infer_out.img
-        world, rank = dist.get_world_size(self.seq_p_group), dist.get_rank(self.seq_p_group)
+        world, rank = comm.group_size(self.seq_p_group), comm.group_rank(self.seq_p_group)
         pad = (world - (img.shape[1] % world)) % world
         if pad > 0:
             img = torch.nn.functional.pad(img, (0, 0, 0, pad))
@@ -437,7 +437,7 @@ class HunyuanVideo15Model:
         return pre_infer_out
 
     def _seq_parallel_post_process(self, x):
-        world = dist.get_world_size(self.seq_p_group)
+        world = comm.group_size(self.seq_p_group)
         gathered = [torch.empty_like(x) for _ in range(world)]
         comm.transport().all_gather(gathered, x.contiguous(), group=self.seq_p_group)
         return torch.cat(gathered, dim=1)

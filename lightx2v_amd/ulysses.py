@@ -200,8 +200,8 @@ class HipUlyssesAttnWeight(_AttnBase):
         tp = comm.transport()
         if q.dim() == 4:
             q, k, v = (t.reshape(-1, t.shape[-2], t.shape[-1]) for t in (q, k, v))
-        world = dist.get_world_size(group)
-        rank = dist.get_rank(group)
+        world = comm.group_size(group)
+        rank = comm.group_rank(group)
         sl, heads, d = q.shape
         if heads % world != 0:
             raise ValueError(f"hip_ulysses: num_heads={heads} is not divisible by the sequence-parallel size {world}")

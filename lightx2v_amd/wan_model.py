@@ -309,7 +309,7 @@ class WanScheduler:
         """fp32 [S_local, head_dim] cos || sin table (scheduler.py:77-114), sharded under Ulysses."""
         table = build_rope_table(grid_sizes, self.head_size, device=self.device)
         if self.seq_p_group is not None:
-            table = shard_rope_table(table, dist.get_world_size(self.seq_p_group), dist.get_rank(self.seq_p_group))
+            table = shard_rope_table(table, comm.group_size(self.seq_p_group), comm.group_rank(self.seq_p_group))
         return table
 
     # scheduler.py:131-167
@@ -509,8 +509,8 @@ class WanModel:
         sch = self.scheduler
         if self.config.get("enable_cfg", True):
             if self.cfg_p_group is not None:
-                assert dist.get_world_size(self.cfg_p_group) == 2, "cfg_p_world_size must be equal to 2"
-                mine = self._infer_cond_uncond(inputs, infer_condition=dist.get_rank(self.cfg_p_group) == 0)
+                assert comm.group_size(self.cfg_p_group) == 2, "cfg_p_world_size must be equal to 2"
+                mine = self._infer_cond_uncond(inputs, infer_condition=comm.group_rank(self.cfg_p_group) == 0)
                 parts = [torch.empty_like(mine) for _ in range(2)]
                 comm.transport().all_gather(parts, mine.contiguous(), group=self.cfg_p_group)
                 cond, uncond = parts
@@ -535,15 +535,29 @@ class WanModel:
 
     def _seq_parallel_pre_process(self, pre_infer_out):
         x = pre_infer_out.x
-        world, rank = dist.get_world_size(self.seq_p_group), dist.get_rank(self.seq_p_group)
+        world, rank = comm.group_size(self.seq_p_group), comm.group_rank(self.seq_p_group)
         pad = (world - (x.shape[0] % world)) % world
         if pad > 0:
             x = torch.nn.functional.pad(x, (0, 0, 0, pad))
         pre_infer_out.x = torch.chunk(x, world, dim=0)[rank].contiguous()
+        # A per-token timestep (Wan2.2 dense ti2v with an image) makes the modulation inputs per-token
+        # too: embed [S, D] and embed0 [S, 6, D] are padded and chunked like the tokens they belong to
+        # (model.py:480-489 does it for model_cls wan2.2 / wan2.2_audio with task i2v / s2v, the cases
+        # that produce them; keyed on the shape here so that every producer of per-token rows is covered).
+        embed, embed0 = pre_infer_out.embed, pre_infer_out.embed0
+        if embed0 is not None and embed0.dim() == 3 and embed0.shape[1] == 6:
+            pad = (world - (embed0.shape[0] % world)) % world
+            if pad > 0:
+                embed0 = torch.nn.functional.pad(embed0, (0, 0, 0, 0, 0, pad))
+            pre_infer_out.embed0 = torch.chunk(embed0, world, dim=0)[rank].contiguous()
+            if embed is not None and embed.dim() == 2 and embed.shape[0] > 1:
+                if pad > 0:
+                    embed = torch.nn.functional.pad(embed, (0, 0, 0, pad))
+                pre_infer_out.embed = torch.chunk(embed, world, dim=0)[rank].contiguous()
         return pre_infer_out
 
     def _seq_parallel_post_process(self, x):
-        world = dist.get_world_size(self.seq_p_group)
+        world = comm.group_size(self.seq_p_group)
         gathered = [torch.empty_like(x) for _ in range(world)]
         comm.transport().all_gather(gathered, x.contiguous(), group=self.seq_p_group)
         return torch.cat(gathered, dim=0)

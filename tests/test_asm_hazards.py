@@ -49,6 +49,13 @@ def test_checker_flags_compiler_traffic_through_the_ring(tmp_path):
     assert _run(tmp_path, between="\tv_accvgpr_write_b32 a248, v11", ring_base=224) == 1
     assert _run(tmp_path, between="\tv_accvgpr_write_b32 a200, v11", ring_base=224) == 0
     assert _run(tmp_path, between="\t;;#ASMSTART\n\tds_read_b128 a[248:251], v1\n\t;;#ASMEND", ring_base=224) == 0
+    # the exp-free fp8 instances carry scale dwords by name in a216-a218 as well: checked with the lower base
+    assert _run(tmp_path, between="\tv_accvgpr_read_b32 v9, a217", ring_base=224) == 0
+    assert _run(tmp_path, between="\tv_accvgpr_read_b32 v9, a217", ring_base=216) == 1
+    p = tmp_path / "k.s"
+    p.write_text(LISTING.format(between="\tv_accvgpr_read_b32 v9, a217", after=""))
+    assert chk.check(str(p), "no_such_kernel", 216) == 0      # --kernel restricts the check to matching symbols
+    assert chk.check(str(p), "kernel", 216) == 1
 
 
 def test_checker_flags_an_lds_read_destination_touched_before_a_wait(tmp_path):

@@ -86,7 +86,7 @@ def _finish():
 H10_CASE = {"grid": (3, 5, 7), "dim": 1280, "heads": 10, "ffn": 2560, "text_len": 77, "seed": 11}  # 5 heads per rank of 2: chunks of 3 + 2
 
 
-def _worker(rank, world, port, out_dir, fused, fp8_comm=False, case=None, rccl=False, fp32_stream=False):
+def _worker(rank, world, port, out_dir, fused, fp8_comm=False, case=None, rccl=False, fp32_stream=False, extra_cfg=None, tag=""):
     dev = _init_rccl(port) if rccl else _init(rank, world, port)
     import lightx2v_amd as L
     from lightx2v_amd import ulysses
@@ -99,9 +99,10 @@ def _worker(rank, world, port, out_dir, fused, fp8_comm=False, case=None, rccl=F
     cfg = {"num_layers": 1, "num_heads": c["heads"], "dim": c["dim"], "task": "t2v", "seq_parallel": True, "seq_p_group": seq_group,
            "parallel": {"seq_p_size": world, "seq_p_attn_type": "hip_ulysses", "seq_p_fp8_comm": fp8_comm}, "fused_block": fused,
            "sensitive_layer_dtype": "fp32" if fp32_stream else "bf16"}
+    cfg.update(extra_cfg or {})
     W = L.WanTransformerWeights(cfg)
     wd = dict(c["w"]); wd.update(c["hw"])
-    W.load(wd); W.to_cuda()
+    W.load({k: v.to(dev) for k, v in wd.items()}); W.to_cuda()   # (the W8A8 schemes quantise on the GPU at load time)
     inf = L.WanTransformerInfer(cfg)
     S = c["S"]
     S_pad = S + (world - S % world) % world
@@ -116,7 +117,7 @@ def _worker(rank, world, port, out_dir, fused, fp8_comm=False, case=None, rccl=F
     out = inf.infer_main_blocks(W.blocks, pre) if fp32_stream else inf.infer_block(W.blocks[0], pre.x, pre)
     assert out.dtype == (torch.float32 if fp32_stream else torch.bfloat16)
     torch.cuda.synchronize()
-    torch.save(out.float().cpu(), os.path.join(out_dir, f"o{rank}_{int(fused)}{'_fp8' if fp8_comm else ''}.pt"))
+    torch.save(out.float().cpu(), os.path.join(out_dir, f"o{rank}_{int(fused)}{'_fp8' if fp8_comm else ''}{tag}.pt"))
     _finish()
 
 
@@ -185,7 +186,7 @@ def test_sequence_parallel_block_fp8_payload(cuda, tmp_path, fused):
     assert cos(got8 - c["x"], ref - c["x"]) >= 0.99
 
 
-def _hy_worker(rank, world, port, out_dir, rccl=False):
+def _hy_worker(rank, world, port, out_dir, rccl=False, extra_cfg=None):
     dev = _init_rccl(port) if rccl else _init(rank, world, port)
     import lightx2v_amd as L
     from lightx2v_amd import ulysses
@@ -196,6 +197,7 @@ def _hy_worker(rank, world, port, out_dir, rccl=False):
     _, seq_idx, seq_group, _ = ulysses.make_groups(1, world)
     cfg = {"mm_double_blocks_depth": c["depth"], "heads_num": c["heads"], "hidden_size": c["dim"], "seq_parallel": True, "seq_p_group": seq_group,
            "parallel": {"seq_p_size": world, "seq_p_attn_type": "hip_ulysses"}}
+    cfg.update(extra_cfg or {})
     W = L.HunyuanVideo15TransformerWeights(cfg)
     wd = {}
     for b in c["blocks"]:
@@ -405,3 +407,158 @@ def test_full_size_exchange_over_rccl_one_rank(cuda, tmp_path):
     # launches of 8 heads and one launch of 40 differ at most in the last bf16 bit of a few outputs
     assert res["max_diff"] <= 2.0 ** -8 * res["max_ref"], res
     assert res["refused"]
+
+
+# ---- BASELINE config 5's composition: W8A8 fp8 Linears and the fp8 attention under sequence parallelism ----
+# (lightx2v/common/ops/attn/ulysses_attn.py:80-118 around a quantised attention module; lightx2v/common/ops/mm/mm_weight.py:901-928
+# behind the output projection that consumes the exchanged attention result)
+FP8_MODES = {"fp8_linears": {"dit_quant_scheme": "hip-fp8"}, "fp8_attn": {"self_attn_1_type": "hip_fp8_attn"},
+             "fp8_both": {"dit_quant_scheme": "hip-fp8", "self_attn_1_type": "hip_fp8_attn"}}
+
+
+def _unsharded_wan_block(c, dev, extra_cfg, pad_to):
+    """The same block in this process without seq_parallel, on the token rows zero-padded to `pad_to`
+    (the padded rows' RoPE entries are zero, like the sharded table's)."""
+    import lightx2v_amd as L
+
+    cfg = {"num_layers": 1, "num_heads": c["heads"], "dim": c["dim"], "task": "t2v", "fused_block": True}
+    cfg.update(extra_cfg)
+    W = L.WanTransformerWeights(cfg)
+    W.load({k: v.to(dev) for k, v in {**c["w"], **c["hw"]}.items()})
+    W.to_cuda()
+    inf = L.WanTransformerInfer(cfg)
+    table = L.build_rope_table(c["grid"], c["dim"] // c["heads"])
+    table = torch.cat([table, table.new_zeros(pad_to - c["S"], table.shape[1])]) if pad_to > c["S"] else table
+    inf.cos_sin = table.contiguous().to(dev)
+    x = torch.zeros(pad_to, c["dim"])
+    x[:c["S"]] = c["x"]
+    pre = L.WanPreInferModuleOutput(embed=c["embed"].to(dev), grid_sizes=c["grid"], x=x.to(torch.bfloat16).to(dev), embed0=c["embed0"].to(dev),
+                                    context=c["context"].to(torch.bfloat16).to(dev))
+    out = inf.infer_block(W.blocks[0], pre.x, pre)
+    torch.cuda.synchronize()
+    return out.float().cpu()[:c["S"]]
+
+
+@pytest.mark.parametrize("mode", sorted(FP8_MODES))
+@pytest.mark.parametrize("rccl", [False, True])
+def test_sequence_parallel_block_with_fp8_linears_and_fp8_attention(cuda, tmp_path, mode, rccl):
+    """The Wan block with `hip-fp8` Linears and / or `hip_fp8_attn` under `seq_parallel`: two ranks on
+    the host-staged transport (10 heads -> chunks of 3 + 2 heads per rank, one padded token), and one
+    rank on RCCL (chunks of 5 + 5).  The fp8 attention plugin re-sizes its workspace per chunk shape;
+    the fp8 output projection takes the gathered operand (its activation quantiser needs whole rows)
+    and the LayerNorms hand e4m3 rows to sharded consumers.  Held to the unsharded run of the SAME
+    arithmetic (head chunks change the launch plan, not the per-head arithmetic: cosine >= 0.99999,
+    delta cosine >= 0.9995) and to the fp32 oracle within the fp8 gate of the unsharded tests."""
+    from oracle import wan_block_ref as R
+    from tests.util import case_inputs, cos
+
+    extra = FP8_MODES[mode]
+    world = 1 if rccl else 2
+    _spawn(_worker, lambda port: (world, port, str(tmp_path), True, False, H10_CASE, rccl, False, extra, "_" + mode), world)
+    c = case_inputs(H10_CASE)
+    S, D = c["S"], c["dim"]
+    got = torch.cat([torch.load(os.path.join(str(tmp_path), f"o{r}_1_{mode}.pt")) for r in range(world)])[:S]
+    pad_to = S + (world - S % world) % world
+    same = _unsharded_wan_block(c, cuda, extra, pad_to)
+    c_same, c_same_delta = cos(got, same), cos(got - c["x"], same - c["x"])
+    xp = torch.zeros(pad_to, D); xp[:S] = c["x"]
+    cs = torch.cat([c["cos_sin"], torch.zeros(pad_to - S, 1, c["cos_sin"].shape[-1], dtype=c["cos_sin"].dtype)])
+    ref = R.block_forward(xp, c["embed0"], c["context"], c["w"], cs, c["heads"])[:S]
+    c_out, c_delta = cos(got, ref), cos(got - c["x"], ref - c["x"])
+    print(f"\nseq-parallel block, {mode}, {'RCCL x1' if rccl else 'host-staged x2'}: vs unsharded same arithmetic {c_same:.7f} / delta {c_same_delta:.6f}; vs fp32 oracle {c_out:.6f} / delta {c_delta:.6f}")
+    assert c_same >= 0.99999 and c_same_delta >= 0.9995
+    assert c_out >= 0.999 and c_delta >= 0.99
+
+
+@pytest.mark.parametrize("mode", ["fp8_linears", "fp8_attn", "fp8_both"])
+@pytest.mark.parametrize("rccl", [False, True])
+def test_hunyuan_double_blocks_sequence_parallel_with_fp8(cuda, tmp_path, mode, rccl):
+    """BASELINE config 5's arithmetic on the HunyuanVideo layout: image rows exchanged, the rank's text
+    rows appended to every head chunk the fp8 attention attends, text outputs gathered along the head
+    axis, fp8 Linears on both streams.  Against the unsharded run of the same arithmetic and the
+    reference's fp32 golden."""
+    import lightx2v_amd as L
+    from tests.test_hy_gpu import _build, _io
+    from tests.test_hy_oracle import hy_case_inputs
+    from tests.util import cos, load_golden
+
+    extra = {"fp8_linears": {"dit_quant_scheme": "hip-fp8"}, "fp8_attn": {"attn_type": "hip_fp8_attn"},
+             "fp8_both": {"dit_quant_scheme": "hip-fp8", "attn_type": "hip_fp8_attn"}}[mode]
+    world = 1 if rccl else 2
+    _spawn(_hy_worker, lambda port: (world, port, str(tmp_path), rccl, extra), world)
+    res = [torch.load(os.path.join(str(tmp_path), f"hy{r}.pt")) for r in range(world)]
+    rec = load_golden("hy_tiny_d256")
+    got = torch.cat([r["final"][0] for r in res])
+    c = hy_case_inputs(rec)
+    W, inf = _build(c, cuda, **extra)
+    same = inf.infer(W, _io(c, cuda))[0].float().cpu()
+    gold = torch.from_numpy(rec["final_out"])
+    print(f"\nHunyuanVideo seq-parallel, {mode}, {'RCCL x1' if rccl else 'host-staged x2'}: vs unsharded same arithmetic {cos(got, same):.6f}; vs reference golden {cos(got, gold):.6f} (unsharded: {cos(same, gold):.6f})")
+    assert cos(got, same) >= 0.9999
+    assert cos(got, gold) >= 0.995
+    if world > 1:
+        assert cos(res[0]["txt"], res[1]["txt"]) >= 0.9999
+
+
+# ---- per-token modulation under sequence parallelism (lightx2v/models/networks/wan/model.py:480-489) ----
+def _ti2v_worker(rank, world, port, out_dir):
+    dev = _init(rank, world, port)
+    import lightx2v_amd as L
+    from lightx2v_amd import ulysses
+    from tests.test_step_oracle import plain_case
+
+    rec, meta, (model,) = plain_case("step_ti2v_d256")
+    _, _, seq_group, _ = ulysses.make_groups(1, world)
+    cfg = {"dim": meta["dim"], "num_heads": meta["heads"], "num_layers": meta["layers"], "ffn_dim": meta["ffn"], "in_dim": 16, "out_dim": 16,
+           "freq_dim": 256, "task": "i2v", "model_cls": "wan2.2", "use_image_encoder": False, "infer_steps": meta["steps"], "sample_shift": meta["shift"],
+           "sample_guide_scale": meta["guide"], "enable_cfg": True, "run_device": "cuda", "keep_latents_dtype_in_scheduler": True,
+           "seq_parallel": True, "seq_p_group": seq_group, "parallel": {"seq_p_size": world, "seq_p_attn_type": "hip_ulysses"}}
+    m = L.WanModel(cfg, weight_dict=dict(model))
+    m.to_cuda()
+    sch = L.WanScheduler(cfg)
+    m.set_scheduler(sch)
+    z = torch.from_numpy(rec["z"])
+    inputs = {"text_encoder_output": {k: torch.from_numpy(rec[k]).to(dev) for k in ("context", "context_null")},
+              "image_encoder_output": {"vae_encoder_out": z.to(dev)}}
+    sch.prepare(meta["seed"], meta["latent_shape"], image_encoder_output=inputs["image_encoder_output"], latents=torch.from_numpy(rec["noise0"]))
+    inputs["image_encoder_output"]["vae_encoder_out"] = None
+    shapes = []
+    real = m._seq_parallel_pre_process
+
+    def spy(pre):
+        out = real(pre)
+        shapes.append((tuple(out.x.shape), tuple(out.embed.shape), tuple(out.embed0.shape)))
+        return out
+
+    m._seq_parallel_pre_process = spy
+    preds = []
+    for i in range(meta["steps"]):
+        sch.step_pre(i)
+        m.infer(inputs)
+        preds.append(sch.noise_pred.float().cpu())
+        sch.step_post()
+    torch.save({"preds": preds, "latents": sch.latents.float().cpu(), "shapes": shapes}, os.path.join(out_dir, f"t{rank}.pt"))
+    _finish()
+
+
+def test_ti2v_per_token_modulation_is_sharded_with_the_tokens(cuda, tmp_path):
+    """Wan2.2 dense ti2v with an image runs a per-token timestep: embed [S, D] and embed0 [S, 6, D] must
+    be padded and chunked over the sequence group together with x, or every rank would hand S-row
+    modulation tensors to kernels working on S/N rows.  Two ranks against the reference's golden trajectory."""
+    import numpy as np
+    from tests.test_step_oracle import plain_case
+    from tests.util import cos, rel_err
+
+    world = 2
+    _spawn(_ti2v_worker, lambda port: (world, port, str(tmp_path)), world)
+    rec, meta, _ = plain_case("step_ti2v_d256")
+    res = [torch.load(os.path.join(str(tmp_path), f"t{r}.pt")) for r in range(world)]
+    for xs, es, e0s in res[0]["shapes"]:
+        assert es[0] == xs[0] and e0s == (xs[0], 6, xs[1]), (xs, es, e0s)
+    for i in range(meta["steps"]):
+        gold = torch.from_numpy(np.asarray(rec[f"noise_pred_{i}"]))
+        for r in range(world):
+            assert cos(res[r]["preds"][i], gold) >= 0.999, (i, r, cos(res[r]["preds"][i], gold))
+            assert torch.equal(res[r]["preds"][i], res[0]["preds"][i]), (i, r)
+    final = torch.from_numpy(np.asarray(rec[f"latents_{meta['steps']}"]))
+    assert rel_err(res[0]["latents"], final) <= 3e-2 and cos(res[0]["latents"], final) >= 0.9995

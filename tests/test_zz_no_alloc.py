@@ -57,3 +57,30 @@ def test_static_scratch_entry_point_rejects_what_does_not_fit(cuda):
     assert rc == -2 and b"fixed array" in lib.lx2v_last_error()
     with pytest.raises(hip.Lx2vError, match="expected shape"):
         hip.attn_fwd_fp8_static(q, k, v, out[:32])
+
+
+def test_static_scratch_entry_point_under_graph_capture(cuda):
+    """What the entry point is for: one warm-up call outside capture (it resolves the device's copy of
+    the array), then the call is recorded into a graph and replayed twice; every replay reproduces
+    the workspace entry point's result bit for bit.  The second shape is long enough per head
+    (60 000 keys) for the round alignment, which a captured launch must leave off."""
+    for s, heads, seed in ((1500, 4, 5), (60000, 1, 6)):
+        q, k, v = _qkv(cuda, s, heads, seed)
+        ref = hip.attn_fwd_fp8(q, k, v)
+        out = torch.empty_like(ref)
+        _call_static(q, k, v, out)                 # outside capture
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                _call_static(q, k, v, out)
+        for _ in range(2):
+            out.fill_(float("nan"))
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref)
+        hip.attn_fwd_fp8(q, k, v)                  # and the eager path still runs afterwards (counters untouched by the replays)
+        torch.cuda.synchronize()
