@@ -12,48 +12,11 @@
 // lane's 32 K bytes go through two v_mfma_i32_16x16x64_i8 (first and second 16 bytes; both operands
 // use the same split, so every K index meets its partner), accumulation is exact in int32 and the
 // accumulators are converted to fp32 in front of the shared epilogue.
-#include <stdlib.h>
-
-#include <type_traits>
-
-#include "common.h"
+#include "gemm_fp8_common.h"
 
 namespace {
 
-constexpr int BM = 256, BN = 256, BK = 128;  // BK in fp8 elements = bytes
 constexpr int NTHREADS = 512;
-constexpr int TILE_BYTES = BM * BK;  // 32 KiB, same for A and W
-constexpr int GROUP_M = 8;               // tile rasterisation: 8 row-panels share one column sweep
-
-typedef int i32x8 __attribute__((ext_vector_type(8)));
-
-struct GemmParams {
-  const uint8_t* A;
-  const uint8_t* W;
-  const float* a_scale;
-  const float* w_scale;
-  const float* bias;
-  uint16_t* C;
-  const uint16_t* resid;
-  const float* gate;
-  int64_t lda, ldw, ldc, ldr;
-  int M, N, K;
-  int tiles_m, tiles_n;
-};
-
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void gbl_void;
-
-LX2V_DEVICE void glds16(const void* g, void* l) {
-  __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)l, 16, 0, 0);
-}
-
-// Bijective remap so that blocks sharing an XCD (same blockIdx % 8) get a contiguous run of tiles.
-LX2V_DEVICE int xcd_remap(int bid, int nwg) {
-  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return base + (bid >> 3);
-}
 
 // Epilogue shared by both schedules: scales, bias and the optional GELU / gate in fp32 on the
 // accumulators -> per-wave LDS image (bf16) -> whole 128-B row segments.
@@ -112,8 +75,6 @@ LX2V_DEVICE void gemm_fp8_epilogue(const GemmParams& p, f32x4 (&acc)[4][8], char
     }
   }
 }
-
-typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 template <int EPI, bool INT8 = false>
 __global__ __launch_bounds__(NTHREADS) void gemm_fp8_kernel(const GemmParams p) {
@@ -446,11 +407,18 @@ static int gemm_w8a8(bool int8, const uint8_t* A, int64_t lda, const float* a_sc
   LX2V_REQUIRE(nwg < (1LL << 31), LX2V_EUNSUP, "gemm_fp8: too many tiles");
   const dim3 grid((unsigned)nwg), block(NTHREADS);
   hipStream_t st = (hipStream_t)stream;
-  // The one-barrier-per-K-tile schedule is the default here: at 14B shapes it measured 2.0-2.24 PFLOP/s
-  // against 1.87-2.11 for the ping-pong schedule (which wins by 10 % on the bf16 GEMM).
-  // Option gemm_kernel = 2 selects the latter (A/B switch).
+  if (int8) LX2V_REQUIRE(K <= 131072, LX2V_EUNSUP, "gemm_int8: K=%lld: the int32 accumulators hold 127 * 127 * K up to K = 131072", (long long)K);
+  // Default (gemm_kernel = 0): the persistent one-wave-per-SIMD kernel.  Its staging addresses rows through
+  // 32-bit buffer offsets, so operands whose extent reaches 4 GiB stay with the 8-wave kernels.
+  if (lx2v_options().gemm_kernel == 0 && M * lda < (1LL << 32) && N * ldw < (1LL << 32)) {
+    const int rc = lx2v_gemm_w8a8_launch_w4(p, int8, epilogue, st);
+    if (rc != LX2V_OK) return rc;
+    LX2V_CHECK_LAUNCH(int8 ? "gemm_int8(w4)" : "gemm_fp8(w4)");
+    return LX2V_OK;
+  }
+  // The 8-wave kernels (gemm_kernel = 1: one barrier per K-tile, 2.0-2.24 PFLOP/s at 14B shapes; 2: the ping-pong
+  // schedule, 1.87-2.11, fp8 only): A/B switches, and the path of operands beyond 4 GiB.
   if (int8) {
-    LX2V_REQUIRE(K <= 131072, LX2V_EUNSUP, "gemm_int8: K=%lld: the int32 accumulators hold 127 * 127 * K up to K = 131072", (long long)K);
     switch (epilogue) {
       case LX2V_EPI_NONE: hipLaunchKernelGGL((gemm_fp8_kernel<LX2V_EPI_NONE, true>), grid, block, 0, st, p); break;
       case LX2V_EPI_GELU_TANH: hipLaunchKernelGGL((gemm_fp8_kernel<LX2V_EPI_GELU_TANH, true>), grid, block, 0, st, p); break;

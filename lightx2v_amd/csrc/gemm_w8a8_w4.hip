@@ -1,0 +1,478 @@
+// W8A8 Linear (fp8 e4m3 or int8 operands, fp32 / int32 accumulation, bf16 out) on MFMA, persistent,
+// one wave per SIMD:  C[M,N] = epilogue((A8[M,K] @ W8[N,K]^T) * a_scale[m] * w_scale[n] + bias).
+//
+// The design of the bf16 kernel in gemm_bf16_w4.hip on one-byte operands.  Workgroup = 4 waves
+// (2 x 2), one per SIMD, each owning a 128 x 128 corner of a 256 x 256 output tile (64 accumulator
+// tuples, 60 of them in the accumulator half of the register file); one workgroup per CU walks its
+// share of the output tiles, so the stream of K-tiles never drains between tiles.  A K-tile is 128
+// bytes of K per row -- the same 32 KiB per operand as the bf16 kernel's 64 elements -- and ONE
+// v_mfma_f32_16x16x128_f8f6f4 per accumulator tuple covers its whole depth (int8: two
+// v_mfma_i32_16x16x64_i8 on the first and second 16 bytes of the lane's 32): half as many LDS-DMA
+// pieces, fragment reads, waits and barriers per FLOP as the bf16 kernel pays.
+//
+// LDS: a ring of five 32 KiB slots; half-tile h = 2 j + o (o = 0: A of K-tile j, o = 1: W of K-tile
+// j) goes through slot h % 5.  Registers: the 8 A fragments and the 8 W fragments of one K-tile
+// (8 registers each, 128 in all, as many as the bf16 kernel's two K-steps).  Per K-tile j:
+//   first half   W fragments 0-3 (the MFMA's A operand: output columns) against all 8 A fragments,
+//                W-major.  Reads W[2..7] of K-tile j -- every read of W(j) precedes X.  The 8 DMA
+//                pieces of A(j + 2) go to the slot W(j - 1) left at the previous barrier.
+//   X            s_waitcnt vmcnt(8) lgkmcnt(0); s_barrier: K-tile j + 1 is complete in LDS.
+//   second half  W fragments 4-7, A-major: A fragment mt meets its last MFMA early, and A[mt] of
+//                K-tile j + 1 is read into its registers right behind that MFMA, so the A reads are
+//                spread over the half; W[0], W[1] of K-tile j + 1 go to the registers the first half
+//                left.  The 8 DMA pieces of W(j + 2) go to the slot of A(j), whose reads all precede X.
+// One instruction class besides the MFMA per MFMA shadow (M0 write, DMA instruction, one fragment's
+// two reads).
+// The slot images and the staging are the bf16 kernel's (128-byte rows, chunk ^= (row >> 1) & 7,
+// raw buffer descriptors: rows past M / N arrive as zeros).
+//
+// Epilogue as in the bf16 kernel (eight passes of 16 rows through the idle W(j) slot as fp32 / int32,
+// eight consecutive columns per lane, 256-byte row segments out), with the two scales applied first:
+// v = acc * a_scale[m] * w_scale[n] + bias, the arithmetic of the 8-wave kernels in gemm_fp8.hip, so
+// results are bit-identical to theirs.
+#include "gemm_fp8_common.h"
+
+namespace {
+
+#ifndef W8_ABL
+#define W8_ABL 0  // timing ablations (wrong results): 1 no LDS-DMA in the loop, 2 no fragment reads, 4 no wait + barrier per K-tile, 8 no epilogue, 16 no MFMAs
+#endif
+constexpr int W4_THREADS = 256;
+constexpr int NSLOT = 5;
+constexpr int W4_LDS = NSLOT * TILE_BYTES;  // all 160 KiB of the CU
+constexpr int W4_GROUP_M = 4;               // row panels per column sweep (the bf16 kernel's measured choice)
+
+template <int N>
+struct IntC {
+  static constexpr int value = N;
+};
+template <int B, int E, class F>
+LX2V_DEVICE void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(IntC<B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
+LX2V_DEVICE void tile_origin_w4(const GemmParams& p, int vbid, int& m0, int& n0) {
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int t = xcd_remap(vbid, nwg);
+  const int group_sz = W4_GROUP_M * p.tiles_n;
+  const int g = t / group_sz;
+  const int first_m = g * W4_GROUP_M;
+  const int gm = min(p.tiles_m - first_m, W4_GROUP_M);
+  const int in_g = t - g * group_sz;
+  m0 = (first_m + in_g % gm) * BM;
+  n0 = (in_g / gm) * BN;
+}
+
+constexpr bool acc_in_agpr(int nt, int mt) { return !(nt == 7 && mt >= 6); }  // 62 of the 64 tuples (the compiler keeps a few accumulator registers to itself)
+
+// acc (+)= W fragment (MFMA A operand: output columns) x A fragment (B operand: rows).
+// FIRST: the K-tile that opens an output tile starts its accumulators from 0.
+// int8: HALF selects the first / second 16 bytes of both fragments (the two calls of a tuple are
+// eight MFMAs apart: the second reads the first one's result).
+template <bool INT8, bool IN_AGPR, bool FIRST, int HALF>
+LX2V_DEVICE void mfma_acc(f32x4& acc, const i32x8& wf, const i32x8& af) {
+  if constexpr (W8_ABL & 16) {
+    asm volatile("" ::"v"(wf), "v"(af));
+  } else if constexpr (!INT8) {
+    if constexpr (FIRST) {
+      if constexpr (IN_AGPR) asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, 0" : "=a"(acc) : "v"(wf), "v"(af));
+      else asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, 0" : "=&v"(acc) : "v"(wf), "v"(af));
+    } else {
+      if constexpr (IN_AGPR) asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0" : "+a"(acc) : "v"(wf), "v"(af));
+      else asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0" : "+v"(acc) : "v"(wf), "v"(af));
+    }
+  } else {
+    const i32x4 w4 = HALF == 0 ? __builtin_shufflevector(wf, wf, 0, 1, 2, 3) : __builtin_shufflevector(wf, wf, 4, 5, 6, 7);
+    const i32x4 a4 = HALF == 0 ? __builtin_shufflevector(af, af, 0, 1, 2, 3) : __builtin_shufflevector(af, af, 4, 5, 6, 7);
+    if constexpr (FIRST && HALF == 0) {
+      if constexpr (IN_AGPR) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, 0" : "=a"(acc) : "v"(w4), "v"(a4));
+      else asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, 0" : "=&v"(acc) : "v"(w4), "v"(a4));
+    } else {
+      if constexpr (IN_AGPR) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(acc) : "v"(w4), "v"(a4));
+      else asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(w4), "v"(a4));
+    }
+  }
+}
+template <bool IN_AGPR>
+LX2V_DEVICE void acc_to_lds(int lds_addr, const f32x4& acc) {
+  if constexpr (IN_AGPR) asm volatile("ds_write_b128 %0, %1" ::"v"(lds_addr), "a"(acc) : "memory");
+  else asm volatile("ds_write_b128 %0, %1" ::"v"(lds_addr), "v"(acc) : "memory");
+}
+
+LX2V_DEVICE u32x4 raw_descriptor(const void* base, int64_t bytes) {
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  u32x4 d;
+  d[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+  d[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));  // stride 0: raw buffer
+  d[2] = __builtin_amdgcn_readfirstlane((uint32_t)(bytes < 0 ? 0 : (bytes > 0xffffffffLL ? 0xffffffffLL : bytes)));  // loads at or past it return 0
+  d[3] = 0x00020000u;
+  return d;
+}
+
+template <int EPI, bool INT8>
+__global__ __launch_bounds__(W4_THREADS) void gemm_w8a8_w4_kernel(const GemmParams p) {
+  __shared__ __attribute__((aligned(16))) char lds[W4_LDS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int grid = gridDim.x;
+  const int nk = p.K / BK;
+
+  // ---- staging: DMA instruction q (0..7) of wave w fills rows 64 w + 8 q .. + 7 of the tile image
+  // (1 KiB of LDS, lane L the 16 bytes at 16 L: row 64 w + 8 q + (L >> 3), position L & 7 holding
+  // source chunk (L & 7) ^ ((row >> 1) & 7)); four pieces share one M0 through the instruction's
+  // 12-bit offset field, which is added to the LDS address and to the memory address alike.
+  auto piece_voff = [&](int q, int64_t ld) __attribute__((always_inline)) -> int {
+    const int row = 64 * wid + 8 * q + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    return (int)(row * ld) + chunk * 16 - (q & 3) * 1024;  // the offset field adds (q & 3) KiB back
+  };
+  int a_pv[8], w_pv[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    a_pv[q] = piece_voff(q, p.lda);
+    w_pv[q] = piece_voff(q, p.ldw);
+    asm volatile("" : "+v"(a_pv[q]), "+v"(w_pv[q]));
+  }
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char*)lds);
+  const uint32_t dma_base = lds_base + 8192 * (uint32_t)wid;
+
+  // DMA cursor: the K-tile staged next, two K-tiles ahead of the one computed.
+  int d_ord = 0;  // ordinal of the cursor's output tile in this workgroup's list
+  int d_kt = 0;
+  u32x4 a_rs, w_rs;
+  // Descriptors of the cursor's tile.  Past the workgroup's last tile they are empty (0 bytes): the
+  // DMA instructions of the stream's last two K-tiles fetch nothing and write zeros into a slot
+  // nobody reads, so the loop body needs no "last tiles" variants.
+  auto d_panel = [&]() __attribute__((always_inline)) {
+    const int vbid = d_ord * grid + (int)blockIdx.x;
+    const bool live = vbid < ntiles;
+    int m0 = 0, n0 = 0;
+    if (live) tile_origin_w4(p, vbid, m0, n0);
+    a_rs = raw_descriptor(p.A + (int64_t)m0 * p.lda, live ? ((int64_t)p.M - m0) * p.lda : 0);
+    w_rs = raw_descriptor(p.W + (int64_t)n0 * p.ldw, live ? ((int64_t)p.N - n0) * p.ldw : 0);
+  };
+  d_panel();
+  auto dma_m0 = [&](uint32_t slot_base, auto dstc) __attribute__((always_inline)) {
+    asm volatile("s_add_u32 m0, %0, %1" ::"s"(slot_base), "i"(decltype(dstc)::value) : "memory", "scc");
+  };
+  auto dma_go = [&](const u32x4& rsrc, int voff, uint32_t soff, auto ofsc) __attribute__((always_inline)) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:%3 lds" ::"v"(voff), "s"(rsrc), "s"(soff), "n"(decltype(ofsc)::value) : "memory");
+  };
+  uint32_t d_soff = 0;  // byte offset of the cursor's K-tile inside a row (same for A and W)
+  auto d_begin = [&]() __attribute__((always_inline)) { d_soff = (uint32_t)d_kt * BK; };
+  auto dma_piece_m0 = [&](uint32_t slot_base, auto qc) __attribute__((always_inline)) {
+    constexpr int q = decltype(qc)::value;
+    if constexpr ((q & 3) == 0) dma_m0(slot_base, IntC<1024 * q>{});
+  };
+  auto dma_piece_go = [&](auto halfc, auto qc) __attribute__((always_inline)) {
+    constexpr int q = decltype(qc)::value;
+    if constexpr (decltype(halfc)::value == 0) dma_go(a_rs, a_pv[q], d_soff, IntC<1024 * (q & 3)>{});
+    else dma_go(w_rs, w_pv[q], d_soff, IntC<1024 * (q & 3)>{});
+  };
+  auto dma_piece = [&](uint32_t slot_base, auto halfc, auto qc) __attribute__((always_inline)) {  // prologue only
+    dma_piece_m0(slot_base, qc);
+    asm volatile("s_nop 0");
+    dma_piece_go(halfc, qc);
+  };
+  auto d_advance = [&]() __attribute__((always_inline)) {  // after the W half of a K-tile
+    ++d_kt;
+    if (d_kt == nk) {
+      d_kt = 0;
+      ++d_ord;
+      d_panel();
+    }
+    // (the descriptors are merged here from two paths; pinned to scalar registers, or the compiler may move the
+    // merge to vector registers, which the DMA statements cannot take)
+    asm volatile("" : "+s"(a_rs), "+s"(w_rs));
+  };
+
+  // ---- fragment read offsets inside a slot image: the lane's 32 K bytes are the two adjacent
+  // 16-byte chunks 2 fq, 2 fq + 1 of row (corner row + fr); mt / nt add 2048 each ----
+  int rd_a[2], rd_w[2];
+  {
+    const int arow = wm * 128 + fr, wrow = wn * 128 + fr;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      rd_a[c] = arow * 128 + (((2 * fq + c) ^ ((arow >> 1) & 7)) << 4);
+      rd_w[c] = wrow * 128 + (((2 * fq + c) ^ ((wrow >> 1) & 7)) << 4);
+    }
+  }
+  auto read_frag = [&](const char* base, const int (&rd)[2], int i) __attribute__((always_inline)) -> i32x8 {
+    const i32x4 lo = *reinterpret_cast<const i32x4*>(base + rd[0] + i * 2048);
+    const i32x4 hi = *reinterpret_cast<const i32x4*>(base + rd[1] + i * 2048);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+
+  f32x4 acc[8][8];  // acc[nt][mt][j] = C'[m = wm*128 + mt*16 + fr][n = wn*128 + nt*16 + fq*4 + j] (int8: the int32 bit patterns)
+  i32x8 fa[8];      // A fragments of the current K-tile (second half: replaced one by one by the next K-tile's)
+  i32x8 fw[8];      // W fragments of the current K-tile (second half: fw[0], fw[1] already the next K-tile's)
+
+  // One K-tile.  sa..sfree: byte offsets of the slots A(j), W(j), A(j+1), W(j+1) and the free one.
+  // Extras ride in the shadow of the MFMA they follow: u = MFMA position inside the half (int8: of the
+  // first MFMA of the pair).
+  auto ktile = [&](auto FIRSTc, int sa, int sw, int sa1, int sw1, int sfree, bool relaxed) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(FIRSTc)::value != 0;
+    const char* lw = lds + sw;
+    const char* la1 = lds + sa1;
+    const char* lw1 = lds + sw1;
+    const uint32_t dfree = dma_base + (uint32_t)sfree, dsa = dma_base + (uint32_t)sa;
+    constexpr bool DMA = !(W8_ABL & 1), RD = !(W8_ABL & 2);
+    // DMA piece q of a half: M0 (pieces 0 and 4) in shadow 4 q, the instruction in shadow 4 q + 1
+    auto dma_extra = [&](uint32_t dslot, auto halfc, auto uc) __attribute__((always_inline)) {
+      constexpr int u = decltype(uc)::value;
+      if constexpr (DMA && (u & 3) == 0) dma_piece_m0(dslot, IntC<u / 4>{});
+      if constexpr (DMA && (u & 3) == 1) dma_piece_go(halfc, IntC<u / 4>{});
+    };
+    // ---- first half: W-major; W[2..7] of this K-tile in shadows 2, 6, 10, ...; DMA of A(j + 2) into the free slot ----
+    d_begin();
+    static_for<0, 4>([&](auto ntc) __attribute__((always_inline)) {
+      constexpr int nt = decltype(ntc)::value;
+      static_for<0, 8>([&](auto mc) __attribute__((always_inline)) {
+        constexpr int mt = decltype(mc)::value, u = 8 * nt + mt;
+        mfma_acc<INT8, acc_in_agpr(nt, mt), FIRST, 0>(acc[nt][mt], fw[nt], fa[mt]);
+        dma_extra(dfree, IntC<0>{}, IntC<u>{});
+        if constexpr (RD && (u & 3) == 2 && u / 4 < 6) fw[2 + u / 4] = read_frag(lw, rd_w, 2 + u / 4);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if constexpr (INT8) {
+        static_for<0, 8>([&](auto mc) __attribute__((always_inline)) {
+          constexpr int mt = decltype(mc)::value;
+          mfma_acc<INT8, acc_in_agpr(nt, mt), FIRST, 1>(acc[nt][mt], fw[nt], fa[mt]);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      }
+    });
+    // ---- X: this wave's DMA except the 8 pieces just issued has landed, its reads of W(j) are done;
+    // behind the barrier that holds for every wave (K-tile j + 1 complete, W(j) and A(j) released).
+    // `relaxed`: the previous K-tile ended in the epilogue of an interior tile, whose memory operations
+    // (at least the 32 stores) are younger than the data waited for: 40 may stay outstanding.
+    if constexpr (!(W8_ABL & 4)) {
+      if (relaxed) asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    // ---- second half: A-major over W[4..7]; A[mt] of K-tile j + 1 behind the last MFMA of A[mt] (shadow 4 mt + 3),
+    // W[0], W[1] of K-tile j + 1 in shadows 2 and 6; DMA of W(j + 2) into the slot of A(j) ----
+    static_for<0, 8>([&](auto mc) __attribute__((always_inline)) {
+      constexpr int mt = decltype(mc)::value;
+      static_for<4, 8>([&](auto ntc) __attribute__((always_inline)) {
+        constexpr int nt = decltype(ntc)::value, u = 4 * mt + (nt - 4);
+        mfma_acc<INT8, acc_in_agpr(nt, mt), FIRST, 0>(acc[nt][mt], fw[nt], fa[mt]);
+        dma_extra(dsa, IntC<1>{}, IntC<u>{});
+        if constexpr (RD && !INT8 && nt == 7) fa[mt] = read_frag(la1, rd_a, mt);
+        if constexpr (RD && (u == 2 || u == 6)) fw[u / 4] = read_frag(lw1, rd_w, u / 4);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if constexpr (INT8) {
+        static_for<4, 8>([&](auto ntc) __attribute__((always_inline)) {
+          constexpr int nt = decltype(ntc)::value;
+          mfma_acc<INT8, acc_in_agpr(nt, mt), FIRST, 1>(acc[nt][mt], fw[nt], fa[mt]);
+          if constexpr (RD && nt == 7) fa[mt] = read_frag(la1, rd_a, mt);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      }
+    });
+    d_advance();
+  };
+
+  // ---- epilogue of the output tile at (m0, n0): eight passes, one per 16-row block mt ----
+  auto epilogue = [&](int m0, int n0, int epi_base) __attribute__((always_inline)) {
+    int fr = lane & 15, fq = lane >> 4;
+    asm volatile("" : "+v"(fr), "+v"(fq));  // (opaque: nothing of this is hoisted in front of the K-loop)
+    const int stg = (int)(size_t)(__attribute__((address_space(3))) char*)lds + epi_base + wid * 8192;
+    int waddr[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) waddr[nt] = stg + fr * 512 + (((nt * 4 + fq) ^ fr) << 4);
+    const int gn = n0 + wn * 128 + fr * 8;  // this lane's eight output columns
+    const bool col_ok = gn < p.N;           // N % 8 == 0: all eight or none
+    float bv[8], gv[8], swv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      bv[j] = 0.f;
+      gv[j] = 1.f;
+      swv[j] = 0.f;
+    }
+    if (col_ok) {
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.w_scale + gn), s1 = *reinterpret_cast<const f32x4*>(p.w_scale + gn + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { swv[j] = s0[j]; swv[4 + j] = s1[j]; }
+      if (p.bias != nullptr) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + gn), b1 = *reinterpret_cast<const f32x4*>(p.bias + gn + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bv[j] = b0[j]; bv[4 + j] = b1[j]; }
+      }
+      if (EPI == LX2V_EPI_RESIDUAL && p.gate != nullptr) {
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gate + gn), g1 = *reinterpret_cast<const f32x4*>(p.gate + gn + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { gv[j] = g0[j]; gv[4 + j] = g1[j]; }
+      }
+    }
+    // the last MFMAs were issued a few cycles ago and the LDS writes below read their results
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(bv[j]), "+v"(gv[j]), "+v"(swv[j]));  // their loads are waited for here, once
+    // The 128 row scales of this wave's corner: two per lane (rows lane and 64 + lane), fetched per pass
+    // with a lane permute -- no memory operation per pass, so no pass waits behind the stores before it.
+    float sa_lane[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) sa_lane[h] = p.a_scale[min(m0 + wm * 128 + 64 * h + lane, p.M - 1)];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) asm volatile("" : "+v"(sa_lane[h]));
+    // Residual rows are loaded one pass ahead (clamped addresses, no branch: the only conditional
+    // operation of a pass is the store).  They live in W fragment variables that are dead between
+    // K-tiles (fw[2..5]: two passes of four 16-byte rows), so the epilogue needs no registers of its
+    // own for them; what those variables hold when the epilogue ends is complete, consumed data.
+    auto load_rows = [&](int mt, i32x8& d0, i32x8& d1) __attribute__((always_inline)) {
+      if constexpr (EPI == LX2V_EPI_RESIDUAL) {
+        i32x4 r[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int gm = min(m0 + wm * 128 + mt * 16 + it * 4 + fq, p.M - 1);
+          r[it] = *reinterpret_cast<const i32x4*>(p.resid + (int64_t)gm * p.ldr + (col_ok ? gn : 0));
+        }
+        d0 = __builtin_shufflevector(r[0], r[1], 0, 1, 2, 3, 4, 5, 6, 7);
+        d1 = __builtin_shufflevector(r[2], r[3], 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+    };
+    load_rows(0, fw[2], fw[3]);
+    static_for<0, 8>([&](auto mtc) __attribute__((always_inline)) {
+      constexpr int mt = decltype(mtc)::value;
+      if constexpr (mt + 1 < 8) load_rows(mt + 1, fw[2 + 2 * ((mt + 1) & 1)], fw[3 + 2 * ((mt + 1) & 1)]);
+      static_for<0, 8>([&](auto ntc) __attribute__((always_inline)) {
+        constexpr int nt = decltype(ntc)::value;
+        acc_to_lds<acc_in_agpr(nt, mt)>(waddr[nt], acc[nt][mt]);
+      });
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = it * 4 + fq;
+        const int gm = m0 + wm * 128 + mt * 16 + r;
+        const char* row = lds + epi_base + wid * 8192 + r * 512;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(row + (((2 * fr) ^ r) << 4));
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(row + (((2 * fr + 1) ^ r) << 4));
+        float v[8];
+        const i32x4 lo_i = __builtin_bit_cast(i32x4, lo), hi_i = __builtin_bit_cast(i32x4, hi);  // int8: the exact int32 sums
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = INT8 ? (float)lo_i[j] : lo[j];
+          v[4 + j] = INT8 ? (float)hi_i[j] : hi[j];
+        }
+        const float sa = __shfl(sa_lane[mt >> 2], (mt & 3) * 16 + r, 64);  // row mt * 16 + r of the corner
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          v[j] = v[j] * sa * swv[j] + bv[j];
+          if (EPI == LX2V_EPI_GELU_TANH) v[j] = gelu_tanh(v[j]);
+          if (EPI == LX2V_EPI_RESIDUAL) v[j] *= gv[j];
+        }
+        if (EPI == LX2V_EPI_RESIDUAL) {
+          float y[8];
+          const i32x8& rr = fw[2 + 2 * (mt & 1) + (it >> 1)];
+          const i32x4 rh = (it & 1) ? __builtin_shufflevector(rr, rr, 4, 5, 6, 7) : __builtin_shufflevector(rr, rr, 0, 1, 2, 3);
+          unpack8(__builtin_bit_cast(u32x4, rh), y);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = (float)(__bf16)v[j] + y[j];  // the product is rounded to bf16 before the add, as in the 8-wave kernels
+        }
+        const u32x4 out = pack8(v);
+        if (gm < p.M && col_ok) *reinterpret_cast<u32x4*>(p.C + (int64_t)gm * p.ldc + gn) = out;
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  // ---- prologue: half-tiles 0..3 (K-tiles 0 and 1 of the stream), then A[0..7], W[0], W[1] of K-tile 0 ----
+  const int my_tiles = (int)blockIdx.x < ntiles ? (ntiles - 1 - (int)blockIdx.x) / grid + 1 : 0;
+  const int64_t total = (int64_t)my_tiles * nk;  // K-tiles in this workgroup's stream
+  if (total == 0) return;
+  static_for<0, 2>([&](auto tc) __attribute__((always_inline)) {
+    constexpr int t = decltype(tc)::value;
+    d_begin();
+    static_for<0, 8>([&](auto qc) __attribute__((always_inline)) { dma_piece(dma_base + (2 * t) * TILE_BYTES, IntC<0>{}, qc); });
+    static_for<0, 8>([&](auto qc) __attribute__((always_inline)) { dma_piece(dma_base + (2 * t + 1) * TILE_BYTES, IntC<1>{}, qc); });
+    d_advance();
+  });
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < 8; ++i) fa[i] = read_frag(lds, rd_a, i);
+  fw[0] = read_frag(lds + TILE_BYTES, rd_w, 0);
+  fw[1] = read_frag(lds + TILE_BYTES, rd_w, 1);
+#pragma unroll
+  for (int i = 2; i < 8; ++i) fw[i] = i32x8{0, 0, 0, 0, 0, 0, 0, 0};
+
+  // ---- the stream ----
+  int ord = 0, kt = 0;   // output tile ordinal and K-tile of stream position j
+  bool relaxed = false;  // the previous K-tile ended in the epilogue of an interior tile (32 stores per wave)
+  int r5 = 0;            // (2 j) % 5: slot of A(j); W(j) r5 + 1, A(j+1) r5 + 2, W(j+1) r5 + 3, free r5 + 4 (all mod 5)
+  auto slot = [&](int k) __attribute__((always_inline)) -> int {
+    const int s5 = r5 + k;
+    return (s5 >= NSLOT ? s5 - NSLOT : s5) * TILE_BYTES;
+  };
+  for (int64_t j = 0; j < total; ++j) {
+    const int sa = slot(0), sw = slot(1), sa1 = slot(2), sw1 = slot(3), sfree = slot(4);
+    if (kt == 0) ktile(IntC<1>{}, sa, sw, sa1, sw1, sfree, relaxed);
+    else ktile(IntC<0>{}, sa, sw, sa1, sw1, sfree, false);
+    relaxed = false;
+    if (++kt == nk) {
+      int m0, n0;
+      tile_origin_w4(p, ord * grid + (int)blockIdx.x, m0, n0);
+      relaxed = m0 + BM <= p.M && n0 + BN <= p.N;
+      if constexpr (!(W8_ABL & 8)) {
+        epilogue(m0, n0, sw);  // W(j)'s slot is idle until A(j + 3) is staged into it, in the next first half ...
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // ... by every wave into every wave's share of the slot: all must have left the epilogue
+      }
+      // The fragment registers that are dead here (fw[2..7]) stay occupied across the epilogue: handed to its
+      // loads and stores, they would be overwritten by the next K-tile's LDS reads while those memory operations
+      // still count as pending, and the compiler would protect them with a vmcnt wait inside the K-loop.
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(fa[i]), "+v"(fw[i]));
+      kt = 0;
+      ++ord;
+    }
+    r5 += 2;
+    if (r5 >= NSLOT) r5 -= NSLOT;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may still be writing this workgroup's LDS when it ends
+}
+
+}  // namespace
+
+// One workgroup per CU (the 160 KiB of LDS allow no second one), never more than there are tiles.
+int lx2v_gemm_w8a8_launch_w4(const lx2v_w8a8::GemmParams& p, bool int8, int epilogue, hipStream_t st) {
+  static int cus_cached[64];
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+    if (cus_cached[dev] == 0) {
+      int v = 0;
+      cus_cached[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    cus = cus_cached[dev];
+  }
+  const int64_t ntiles = (int64_t)p.tiles_m * p.tiles_n;
+  const dim3 grid((unsigned)(ntiles < cus ? ntiles : cus)), block(W4_THREADS);
+  if (int8) {
+    switch (epilogue) {
+      case LX2V_EPI_NONE: hipLaunchKernelGGL((gemm_w8a8_w4_kernel<LX2V_EPI_NONE, true>), grid, block, 0, st, p); break;
+      case LX2V_EPI_GELU_TANH: hipLaunchKernelGGL((gemm_w8a8_w4_kernel<LX2V_EPI_GELU_TANH, true>), grid, block, 0, st, p); break;
+      default: hipLaunchKernelGGL((gemm_w8a8_w4_kernel<LX2V_EPI_RESIDUAL, true>), grid, block, 0, st, p); break;
+    }
+  } else {
+    switch (epilogue) {
+      case LX2V_EPI_NONE: hipLaunchKernelGGL((gemm_w8a8_w4_kernel<LX2V_EPI_NONE, false>), grid, block, 0, st, p); break;
+      case LX2V_EPI_GELU_TANH: hipLaunchKernelGGL((gemm_w8a8_w4_kernel<LX2V_EPI_GELU_TANH, false>), grid, block, 0, st, p); break;
+      default: hipLaunchKernelGGL((gemm_w8a8_w4_kernel<LX2V_EPI_RESIDUAL, false>), grid, block, 0, st, p); break;
+    }
+  }
+  return LX2V_OK;
+}

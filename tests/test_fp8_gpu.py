@@ -61,32 +61,48 @@ def test_gemm_fp8_matches_quantised_domain_product(cuda, M, N, K):
     assert cos(out, R.linear(a.float(), w.float(), bias)) >= 0.999
 
 
-@pytest.mark.parametrize("M,N,K,epi", [(3000, 2048, 2048, "none"), (1111, 1536, 8960, "gelu"), (2000, 5120, 5120, "resid"), (700, 512, 384, "none")])
-def test_gemm_fp8_schedules_agree_bitwise(cuda, M, N, K, epi, options):
-    """The ping-pong schedule accumulates in the same order as the one-barrier schedule: bit-identical
-    results, across repeated launches with other traffic in flight."""
-    aq, a_s = R.quant_fp8_rowwise(_rand((M, K), 60))
-    wq, w_s = R.quant_fp8_rowwise(_rand((N, K), 61, 0.05))
-    bias = (torch.randn(N, generator=torch.Generator().manual_seed(62)) * 0.1).to(cuda)
-    gate = torch.randn(N, generator=torch.Generator().manual_seed(63)).to(cuda)
-    resid = _rand((M, N), 64).to(cuda)
-    args = (aq.to(cuda), a_s.to(cuda), wq.to(cuda), w_s.to(cuda), bias)
+@pytest.mark.parametrize("int8", [False, True])
+@pytest.mark.parametrize("M,N,K,epi", [(3000, 2048, 2048, "none"), (1111, 1536, 8960, "gelu"), (2000, 5120, 5120, "resid"), (700, 512, 384, "none"),
+                                       (257, 264, 128, "resid"),        # one K-tile per output tile, ragged M and N
+                                       (33, 8, 256, "gelu"),            # a single, mostly empty tile
+                                       (20000, 1536, 640, "none"),      # odd number of K-tiles (5), 474 tiles: two per workgroup, the last round partial
+                                       (75600, 5120, 5120, "resid"),    # the 14B output projection: 5920 tiles, 23-24 per workgroup of the persistent kernel
+                                       (40000, 13824, 2048, "gelu")])   # many tiles of few K-tiles each (16): epilogue-heavy
+def test_gemm_w8a8_schedules_agree_bitwise(cuda, M, N, K, epi, int8, options):
+    """The persistent one-wave-per-SIMD kernel (the default), the one-barrier 8-wave kernel and (fp8) the
+    ping-pong schedule accumulate each output in the same order and share the epilogue arithmetic:
+    bit-identical results, across repeated launches with other traffic in flight."""
+    g = torch.Generator(device=cuda).manual_seed(60 + M % 97)
+    a = torch.randn(M, K, generator=g, device=cuda, dtype=torch.float32).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g, device=cuda, dtype=torch.float32) * 0.05).to(torch.bfloat16)
+    quant = hip.quant_int8_rowwise if int8 else hip.quant_fp8_rowwise
+    gemm = hip.gemm_int8 if int8 else hip.gemm_fp8
+    aq, a_s = quant(a)
+    wq, w_s = quant(w)
+    bias = torch.randn(N, generator=g, device=cuda) * 0.1
+    gate = torch.randn(N, generator=g, device=cuda)
+    resid = torch.randn(M, N, generator=g, device=cuda, dtype=torch.float32).to(torch.bfloat16) if epi == "resid" else None
+    del a, w
+    args = (aq, a_s, wq, w_s, bias)
 
     def run():
         if epi == "gelu":
-            return hip.gemm_fp8(*args, epilogue=hip.EPI_GELU_TANH)
+            return gemm(*args, epilogue=hip.EPI_GELU_TANH)
         if epi == "resid":
-            return hip.gemm_fp8(*args, epilogue=hip.EPI_RESIDUAL, resid=resid.clone(), gate=gate)
-        return hip.gemm_fp8(*args)
+            return gemm(*args, epilogue=hip.EPI_RESIDUAL, resid=resid.clone(), gate=gate)
+        return gemm(*args)
 
-    options(gemm_kernel=0)
+    options(gemm_kernel=1)  # one barrier per K-tile, 8 waves
     ref = run()
-    options(gemm_kernel=2)  # the ping-pong schedule
+    assert bool(torch.isfinite(ref).all())
     noise = torch.empty(64 << 20, dtype=torch.uint8, device=cuda)
-    for i in range(6):
-        if i % 2:
-            noise.fill_(i)
-        assert torch.equal(run(), ref), i
+    for kernel in (0, 2) if not int8 else (0,):   # persistent (default); ping-pong (fp8 only)
+        options(gemm_kernel=kernel)
+        for i in range(4):
+            if i % 2:
+                noise.fill_(i)
+            got = run()
+            assert torch.equal(got, ref), (kernel, i, int((got != ref).sum()), float((got.float() - ref.float()).abs().max()))
 
 
 def test_gemm_fp8_epilogues_and_plugin(cuda):
