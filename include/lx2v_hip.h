@@ -308,6 +308,13 @@ int lx2v_attn_fwd_fp8_static(const uint16_t* q, int64_t ldq, const uint16_t* k, 
  * FloatQuantizer("e4m3") weight path  mm_weight.py:312-320, lightx2v/utils/quant_utils.py:132-161. */
 int lx2v_quant_fp8_rowwise(const uint16_t* x, int64_t ldx, uint8_t* out, int64_t ldo, float* scale,
                            int64_t rows, int dim, void* stream);
+/* The same from a source whose columns are stored as segments (`kseg` as in lx2v_gemm_bf16; NULL = plain
+ * rows): the sequence-parallel attention result in its receive layout is quantised straight into the
+ * plain [rows, dim] operand of lx2v_gemm_fp8, so the W8A8 output projection needs no gather copy either
+ * (what the reference assembles with .contiguous() copies, lightx2v/common/ops/attn/utils/all2all.py:70-87,
+ * before mm_weight.py:492-501 quantises it). */
+int lx2v_quant_fp8_rowwise_kseg(const uint16_t* x, int64_t ldx, const lx2v_kseg* kseg, uint8_t* out, int64_t ldo,
+                                float* scale, int64_t rows, int dim, void* stream);
 
 /* ---- inverse for the fp8 Ulysses payload: out[r,:] = bf16(e4m3(q[r,:]) * bf16(scale[r])) --------
  * (the value of `q.to(bf16) * scale.to(bf16)`).  With lx2v_quant_fp8_rowwise on rows of head_dim
@@ -337,6 +344,9 @@ int lx2v_gemm_fp8(const uint8_t* A, int64_t lda, const float* a_scale, const uin
  *   lightx2v/common/ops/mm/mm_weight.py:322-330, lightx2v/utils/quant_utils.py:39-49,85-92,111-113. */
 int lx2v_quant_int8_rowwise(const uint16_t* x, int64_t ldx, int8_t* out, int64_t ldo, float* scale,
                             int64_t rows, int dim, int weight_mode, void* stream);
+/* Activation form (weight_mode 0) from a segmented source, as lx2v_quant_fp8_rowwise_kseg. */
+int lx2v_quant_int8_rowwise_kseg(const uint16_t* x, int64_t ldx, const lx2v_kseg* kseg, int8_t* out, int64_t ldo,
+                                 float* scale, int64_t rows, int dim, void* stream);
 
 /* ---- C[M,N] = epilogue((A8 @ W8^T) * a_scale[m] * w_scale[n] + bias), bf16 out ---------------
  * lx2v_gemm_fp8 with int8 operands: the products are accumulated exactly in int32, converted to fp32

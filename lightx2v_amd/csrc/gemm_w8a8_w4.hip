@@ -72,11 +72,17 @@ constexpr bool acc_in_agpr(int nt, int mt) { return !(nt == 7 && mt >= 6); }  //
 // FIRST: the K-tile that opens an output tile starts its accumulators from 0.
 // int8: HALF selects the first / second 16 bytes of both fragments (the two calls of a tuple are
 // eight MFMAs apart: the second reads the first one's result).
+// A fragment = the lane's 32 K bytes as two 16-byte halves (two LDS reads, issued in two MFMA shadows).
+struct Frag8 {
+  i32x4 lo, hi;
+};
 template <bool INT8, bool IN_AGPR, bool FIRST, int HALF>
-LX2V_DEVICE void mfma_acc(f32x4& acc, const i32x8& wf, const i32x8& af) {
+LX2V_DEVICE void mfma_acc(f32x4& acc, const Frag8& wfr, const Frag8& afr) {
   if constexpr (W8_ABL & 16) {
-    asm volatile("" ::"v"(wf), "v"(af));
+    asm volatile("" ::"v"(wfr.lo), "v"(wfr.hi), "v"(afr.lo), "v"(afr.hi));
   } else if constexpr (!INT8) {
+    const i32x8 wf = __builtin_shufflevector(wfr.lo, wfr.hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    const i32x8 af = __builtin_shufflevector(afr.lo, afr.hi, 0, 1, 2, 3, 4, 5, 6, 7);
     if constexpr (FIRST) {
       if constexpr (IN_AGPR) asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, 0" : "=a"(acc) : "v"(wf), "v"(af));
       else asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, 0" : "=&v"(acc) : "v"(wf), "v"(af));
@@ -85,8 +91,8 @@ LX2V_DEVICE void mfma_acc(f32x4& acc, const i32x8& wf, const i32x8& af) {
       else asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0" : "+v"(acc) : "v"(wf), "v"(af));
     }
   } else {
-    const i32x4 w4 = HALF == 0 ? __builtin_shufflevector(wf, wf, 0, 1, 2, 3) : __builtin_shufflevector(wf, wf, 4, 5, 6, 7);
-    const i32x4 a4 = HALF == 0 ? __builtin_shufflevector(af, af, 0, 1, 2, 3) : __builtin_shufflevector(af, af, 4, 5, 6, 7);
+    const i32x4 w4 = HALF == 0 ? wfr.lo : wfr.hi;
+    const i32x4 a4 = HALF == 0 ? afr.lo : afr.hi;
     if constexpr (FIRST && HALF == 0) {
       if constexpr (IN_AGPR) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, 0" : "=a"(acc) : "v"(w4), "v"(a4));
       else asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, 0" : "=&v"(acc) : "v"(w4), "v"(a4));
@@ -206,15 +212,13 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_w8a8_w4_kernel(const GemmPara
       rd_w[c] = wrow * 128 + (((2 * fq + c) ^ ((wrow >> 1) & 7)) << 4);
     }
   }
-  auto read_frag = [&](const char* base, const int (&rd)[2], int i) __attribute__((always_inline)) -> i32x8 {
-    const i32x4 lo = *reinterpret_cast<const i32x4*>(base + rd[0] + i * 2048);
-    const i32x4 hi = *reinterpret_cast<const i32x4*>(base + rd[1] + i * 2048);
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  auto read_half = [&](const char* base, const int (&rd)[2], int i, int c) __attribute__((always_inline)) -> i32x4 {
+    return *reinterpret_cast<const i32x4*>(base + rd[c] + i * 2048);
   };
 
   f32x4 acc[8][8];  // acc[nt][mt][j] = C'[m = wm*128 + mt*16 + fr][n = wn*128 + nt*16 + fq*4 + j] (int8: the int32 bit patterns)
-  i32x8 fa[8];      // A fragments of the current K-tile (second half: replaced one by one by the next K-tile's)
-  i32x8 fw[8];      // W fragments of the current K-tile (second half: fw[0], fw[1] already the next K-tile's)
+  Frag8 fa[8];      // A fragments of the current K-tile (second half: replaced one by one by the next K-tile's)
+  Frag8 fw[8];      // W fragments of the current K-tile (second half: fw[0], fw[1] already the next K-tile's)
 
   // One K-tile.  sa..sfree: byte offsets of the slots A(j), W(j), A(j+1), W(j+1) and the free one.
   // Extras ride in the shadow of the MFMA they follow: u = MFMA position inside the half (int8: of the
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_w8a8_w4_kernel(const GemmPara
       if constexpr (DMA && (u & 3) == 0) dma_piece_m0(dslot, IntC<u / 4>{});
       if constexpr (DMA && (u & 3) == 1) dma_piece_go(halfc, IntC<u / 4>{});
     };
-    // ---- first half: W-major; W[2..7] of this K-tile in shadows 2, 6, 10, ...; DMA of A(j + 2) into the free slot ----
+    // ---- first half: W-major; the two reads of W[2 + i] of this K-tile in shadows 4 i + 2, 4 i + 3; DMA of A(j + 2) into the free slot ----
     d_begin();
     static_for<0, 4>([&](auto ntc) __attribute__((always_inline)) {
       constexpr int nt = decltype(ntc)::value;
@@ -240,7 +244,8 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_w8a8_w4_kernel(const GemmPara
         constexpr int mt = decltype(mc)::value, u = 8 * nt + mt;
         mfma_acc<INT8, acc_in_agpr(nt, mt), FIRST, 0>(acc[nt][mt], fw[nt], fa[mt]);
         dma_extra(dfree, IntC<0>{}, IntC<u>{});
-        if constexpr (RD && (u & 3) == 2 && u / 4 < 6) fw[2 + u / 4] = read_frag(lw, rd_w, 2 + u / 4);
+        if constexpr (RD && (u & 3) == 2 && u / 4 < 6) fw[2 + u / 4].lo = read_half(lw, rd_w, 2 + u / 4, 0);
+        if constexpr (RD && (u & 3) == 3 && u / 4 < 6) fw[2 + u / 4].hi = read_half(lw, rd_w, 2 + u / 4, 1);
         __builtin_amdgcn_sched_barrier(0);
       });
       if constexpr (INT8) {
@@ -261,27 +266,48 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_w8a8_w4_kernel(const GemmPara
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     }
-    // ---- second half: A-major over W[4..7]; A[mt] of K-tile j + 1 behind the last MFMA of A[mt] (shadow 4 mt + 3),
-    // W[0], W[1] of K-tile j + 1 in shadows 2 and 6; DMA of W(j + 2) into the slot of A(j) ----
+    // ---- second half: A-major over W[4..7]; DMA of W(j + 2) into the slot of A(j).  A[mt] of K-tile j + 1 goes out
+    // behind the last MFMA of A[mt]: first half in shadow 4 mt + 3, second half in shadow 4 mt + 6 (one LDS read
+    // fills an MFMA shadow; two in one shadow hold the next MFMA back); W[0], W[1] of K-tile j + 1 in shadows 4, 8, 12, 20 ----
+    auto second_extra = [&](auto uc) __attribute__((always_inline)) {
+      constexpr int u = decltype(uc)::value;
+      dma_extra(dsa, IntC<1>{}, uc);
+      if constexpr (RD) {
+        if constexpr ((u & 3) == 3) fa[u / 4].lo = read_half(la1, rd_a, u / 4, 0);
+        if constexpr ((u & 3) == 2 && u >= 6) fa[u / 4 - 1].hi = read_half(la1, rd_a, u / 4 - 1, 1);
+        if constexpr (u == 4) fw[0].lo = read_half(lw1, rd_w, 0, 0);
+        if constexpr (u == 8) fw[0].hi = read_half(lw1, rd_w, 0, 1);
+        if constexpr (u == 12) fw[1].lo = read_half(lw1, rd_w, 1, 0);
+        if constexpr (u == 20) fw[1].hi = read_half(lw1, rd_w, 1, 1);
+      }
+    };
     static_for<0, 8>([&](auto mc) __attribute__((always_inline)) {
       constexpr int mt = decltype(mc)::value;
-      static_for<4, 8>([&](auto ntc) __attribute__((always_inline)) {
-        constexpr int nt = decltype(ntc)::value, u = 4 * mt + (nt - 4);
-        mfma_acc<INT8, acc_in_agpr(nt, mt), FIRST, 0>(acc[nt][mt], fw[nt], fa[mt]);
-        dma_extra(dsa, IntC<1>{}, IntC<u>{});
-        if constexpr (RD && !INT8 && nt == 7) fa[mt] = read_frag(la1, rd_a, mt);
-        if constexpr (RD && (u == 2 || u == 6)) fw[u / 4] = read_frag(lw1, rd_w, u / 4);
-        __builtin_amdgcn_sched_barrier(0);
-      });
-      if constexpr (INT8) {
+      if constexpr (!INT8) {
+        static_for<4, 8>([&](auto ntc) __attribute__((always_inline)) {
+          constexpr int nt = decltype(ntc)::value;
+          mfma_acc<INT8, acc_in_agpr(nt, mt), FIRST, 0>(acc[nt][mt], fw[nt], fa[mt]);
+          second_extra(IntC<4 * mt + (nt - 4)>{});
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      } else {
+        // int8: the pair of MFMAs of a tuple four MFMAs apart; the extras ride behind the second pass, whose last
+        // MFMA is the last use of A[mt] (extras of the odd positions behind the first pass: one per shadow)
+        static_for<4, 8>([&](auto ntc) __attribute__((always_inline)) {
+          constexpr int nt = decltype(ntc)::value;
+          mfma_acc<INT8, acc_in_agpr(nt, mt), FIRST, 0>(acc[nt][mt], fw[nt], fa[mt]);
+          if constexpr (nt == 4 || nt == 5) second_extra(IntC<4 * mt + (nt - 4)>{});   // M0 / DMA / W' reads: nothing of A[mt]
+          __builtin_amdgcn_sched_barrier(0);
+        });
         static_for<4, 8>([&](auto ntc) __attribute__((always_inline)) {
           constexpr int nt = decltype(ntc)::value;
           mfma_acc<INT8, acc_in_agpr(nt, mt), FIRST, 1>(acc[nt][mt], fw[nt], fa[mt]);
-          if constexpr (RD && nt == 7) fa[mt] = read_frag(la1, rd_a, mt);
+          if constexpr (nt == 6 || nt == 7) second_extra(IntC<4 * mt + (nt - 4)>{});   // position 4 mt + 2: hi of A[mt - 1]; 4 mt + 3: lo of A[mt], behind its last use
           __builtin_amdgcn_sched_barrier(0);
         });
       }
     });
+    if constexpr (RD) fa[7].hi = read_half(la1, rd_a, 7, 1);
     d_advance();
   };
 
@@ -332,7 +358,7 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_w8a8_w4_kernel(const GemmPara
     // operation of a pass is the store).  They live in W fragment variables that are dead between
     // K-tiles (fw[2..5]: two passes of four 16-byte rows), so the epilogue needs no registers of its
     // own for them; what those variables hold when the epilogue ends is complete, consumed data.
-    auto load_rows = [&](int mt, i32x8& d0, i32x8& d1) __attribute__((always_inline)) {
+    auto load_rows = [&](int mt, Frag8& d0, Frag8& d1) __attribute__((always_inline)) {
       if constexpr (EPI == LX2V_EPI_RESIDUAL) {
         i32x4 r[4];
 #pragma unroll
@@ -340,8 +366,10 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_w8a8_w4_kernel(const GemmPara
           const int gm = min(m0 + wm * 128 + mt * 16 + it * 4 + fq, p.M - 1);
           r[it] = *reinterpret_cast<const i32x4*>(p.resid + (int64_t)gm * p.ldr + (col_ok ? gn : 0));
         }
-        d0 = __builtin_shufflevector(r[0], r[1], 0, 1, 2, 3, 4, 5, 6, 7);
-        d1 = __builtin_shufflevector(r[2], r[3], 0, 1, 2, 3, 4, 5, 6, 7);
+        d0.lo = r[0];
+        d0.hi = r[1];
+        d1.lo = r[2];
+        d1.hi = r[3];
       }
     };
     load_rows(0, fw[2], fw[3]);
@@ -375,8 +403,8 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_w8a8_w4_kernel(const GemmPara
         }
         if (EPI == LX2V_EPI_RESIDUAL) {
           float y[8];
-          const i32x8& rr = fw[2 + 2 * (mt & 1) + (it >> 1)];
-          const i32x4 rh = (it & 1) ? __builtin_shufflevector(rr, rr, 4, 5, 6, 7) : __builtin_shufflevector(rr, rr, 0, 1, 2, 3);
+          const Frag8& rr = fw[2 + 2 * (mt & 1) + (it >> 1)];
+          const i32x4 rh = (it & 1) ? rr.hi : rr.lo;
           unpack8(__builtin_bit_cast(u32x4, rh), y);
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = (float)(__bf16)v[j] + y[j];  // the product is rounded to bf16 before the add, as in the 8-wave kernels
@@ -404,11 +432,16 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_w8a8_w4_kernel(const GemmPara
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 #pragma unroll
-  for (int i = 0; i < 8; ++i) fa[i] = read_frag(lds, rd_a, i);
-  fw[0] = read_frag(lds + TILE_BYTES, rd_w, 0);
-  fw[1] = read_frag(lds + TILE_BYTES, rd_w, 1);
+  for (int i = 0; i < 8; ++i) {
+    fa[i].lo = read_half(lds, rd_a, i, 0);
+    fa[i].hi = read_half(lds, rd_a, i, 1);
+    fw[i].lo = fw[i].hi = i32x4{0, 0, 0, 0};
+  }
 #pragma unroll
-  for (int i = 2; i < 8; ++i) fw[i] = i32x8{0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 2; ++i) {
+    fw[i].lo = read_half(lds + TILE_BYTES, rd_w, i, 0);
+    fw[i].hi = read_half(lds + TILE_BYTES, rd_w, i, 1);
+  }
 
   // ---- the stream ----
   int ord = 0, kt = 0;   // output tile ordinal and K-tile of stream position j
@@ -436,7 +469,7 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_w8a8_w4_kernel(const GemmPara
       // loads and stores, they would be overwritten by the next K-tile's LDS reads while those memory operations
       // still count as pending, and the compiler would protect them with a vmcnt wait inside the K-loop.
 #pragma unroll
-      for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(fa[i]), "+v"(fw[i]));
+      for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(fa[i].lo), "+v"(fa[i].hi), "+v"(fw[i].lo), "+v"(fw[i].hi));
       kt = 0;
       ++ord;
     }

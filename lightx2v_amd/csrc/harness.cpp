@@ -263,6 +263,7 @@ int main(int argc, char** argv) {
   if (!strcmp(what, "selfattn")) bench_attn(S, H, iters);
   if (!strcmp(what, "selfattn8")) bench_attn_fp8(S, H, iters);
   if (!strcmp(what, "gemm1")) bench_gemm(S, D, D, 0, iters);
+  if (!strcmp(what, "gemm8_1")) bench_gemm_fp8(S, D, D, 0, iters);
   if (!strcmp(what, "attn") || !strcmp(what, "all")) {
     bench_attn(S, H, iters);
     bench_attn(S, H, iters, 512);

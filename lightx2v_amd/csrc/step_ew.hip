@@ -169,18 +169,32 @@ __global__ __launch_bounds__(256) void cfg_combine_kernel(float* out, const floa
 // (64 = one row per wave; short rows such as one head of 128 values take 16 lanes, four rows per
 // wave); two sweeps over the row (absmax, then convert), the second one served by L2 -- rows can be
 // wider than the register-resident row kernels allow (FFN inner dim).
-__global__ __launch_bounds__(256) void quant_fp8_rowwise_kernel(const uint16_t* __restrict__ x, int64_t ldx, uint8_t* __restrict__ out, int64_t ldo,
+// A source row whose columns are stored as segments (lx2v_kseg; seg == 0: a plain row).  All segment
+// widths are multiples of 8, so a 16-byte chunk never straddles two segments.
+struct SegSrc {
+  int64_t seg, stride, split, seg2, stride2, base2, lda2;
+};
+LX2V_DEVICE const uint16_t* seg_chunk(const uint16_t* x, int64_t ldx, const SegSrc& g, int64_t row, int col) {
+  if (g.seg == 0) return x + row * ldx + col;
+  if (g.split == 0 || col < g.split) {
+    const int64_t s = col / g.seg;
+    return x + s * g.stride + row * ldx + (col - s * g.seg);
+  }
+  const int64_t c2 = col - g.split, t = c2 / g.seg2;
+  return x + g.base2 + t * g.stride2 + row * g.lda2 + (c2 - t * g.seg2);
+}
+
+__global__ __launch_bounds__(256) void quant_fp8_rowwise_kernel(const uint16_t* __restrict__ x, int64_t ldx, const SegSrc src, uint8_t* __restrict__ out, int64_t ldo,
                                                                 float* __restrict__ scale, int64_t rows, int dim, int lpr) {
   const int lane = threadIdx.x & 63;
   const int l = lane & (lpr - 1);
   const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / lpr) + lane / lpr;
   if (row >= rows) return;
-  const uint16_t* xr = x + row * ldx;
   const int nchunks = dim >> 3;
   float amax = 0.f;
   for (int ch = l; ch < nchunks; ch += lpr) {
     float f[8];
-    unpack8(*reinterpret_cast<const u32x4*>(xr + (int64_t)ch * 8), f);
+    unpack8(*reinterpret_cast<const u32x4*>(seg_chunk(x, ldx, src, row, ch * 8)), f);
 #pragma unroll
     for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(f[i]));
   }
@@ -191,7 +205,7 @@ __global__ __launch_bounds__(256) void quant_fp8_rowwise_kernel(const uint16_t* 
   uint8_t* orow = out + row * ldo;
   for (int ch = l; ch < nchunks; ch += lpr) {
     float f[8];
-    unpack8(*reinterpret_cast<const u32x4*>(xr + (int64_t)ch * 8), f);
+    unpack8(*reinterpret_cast<const u32x4*>(seg_chunk(x, ldx, src, row, ch * 8)), f);
     int lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, 0, false);
     lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, lo, true);
     int hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * inv, f[5] * inv, 0, false);
@@ -205,18 +219,17 @@ __global__ __launch_bounds__(256) void quant_fp8_rowwise_kernel(const uint16_t* 
 //     out = rint(x * (127 / max|x[r,:]|)); a row of zeros gets scale 0 and zeros.
 //   weight_mode 1 (weights; the reference's IntegerQuantizer(8, True, "per_channel"), lightx2v/utils/quant_utils.py:43-49,111-113):
 //     scale[r] = max(max|x[r,:]|, 1e-5) / 127, out = rint(x / scale[r]).
-__global__ __launch_bounds__(256) void quant_int8_rowwise_kernel(const uint16_t* __restrict__ x, int64_t ldx, int8_t* __restrict__ out, int64_t ldo,
+__global__ __launch_bounds__(256) void quant_int8_rowwise_kernel(const uint16_t* __restrict__ x, int64_t ldx, const SegSrc src, int8_t* __restrict__ out, int64_t ldo,
                                                                  float* __restrict__ scale, int64_t rows, int dim, int lpr, int weight_mode) {
   const int lane = threadIdx.x & 63;
   const int l = lane & (lpr - 1);
   const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / lpr) + lane / lpr;
   if (row >= rows) return;
-  const uint16_t* xr = x + row * ldx;
   const int nchunks = dim >> 3;
   float amax = 0.f;
   for (int ch = l; ch < nchunks; ch += lpr) {
     float f[8];
-    unpack8(*reinterpret_cast<const u32x4*>(xr + (int64_t)ch * 8), f);
+    unpack8(*reinterpret_cast<const u32x4*>(seg_chunk(x, ldx, src, row, ch * 8)), f);
 #pragma unroll
     for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(f[i]));
   }
@@ -227,7 +240,7 @@ __global__ __launch_bounds__(256) void quant_int8_rowwise_kernel(const uint16_t*
   int8_t* orow = out + row * ldo;
   for (int ch = l; ch < nchunks; ch += lpr) {
     float f[8];
-    unpack8(*reinterpret_cast<const u32x4*>(xr + (int64_t)ch * 8), f);
+    unpack8(*reinterpret_cast<const u32x4*>(seg_chunk(x, ldx, src, row, ch * 8)), f);
     uint32_t w[2] = {0u, 0u};
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -373,36 +386,63 @@ extern "C" int lx2v_cfg_combine_f32(float* out, const float* cond, const float* 
   return LX2V_OK;
 }
 
-extern "C" int lx2v_quant_fp8_rowwise(const uint16_t* x, int64_t ldx, uint8_t* out, int64_t ldo, float* scale, int64_t rows, int dim, void* stream) {
-  LX2V_REQUIRE(rows == 0 || (x && out && scale), LX2V_EINVAL, "quant_fp8: null tensor");
-  LX2V_REQUIRE(rows >= 0 && dim > 0 && dim % 8 == 0, LX2V_EINVAL, "quant_fp8: dim=%d must be a positive multiple of 8", dim);
-  LX2V_REQUIRE(ldx % 8 == 0 && ldo % 8 == 0 && ldx >= dim && ldo >= dim, LX2V_EINVAL, "quant_fp8: row strides must be multiples of 8 and >= dim");
-  LX2V_REQUIRE(lx2v_aligned16(x) && (reinterpret_cast<uintptr_t>(out) & 7u) == 0, LX2V_EINVAL, "quant_fp8: x must be 16-byte, out 8-byte aligned");
-  if (rows == 0) return LX2V_OK;
-  const int nchunks = dim >> 3;
-  int lpr = 64;
-  if (nchunks <= 32 && (nchunks & (nchunks - 1)) == 0) lpr = nchunks;  // short rows share a wave
-  const int64_t rows_per_block = 4 * (64 / lpr);
-  hipLaunchKernelGGL(quant_fp8_rowwise_kernel, dim3((unsigned)((rows + rows_per_block - 1) / rows_per_block)), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo,
-                     scale, rows, dim, lpr);
-  LX2V_CHECK_LAUNCH("quant_fp8");
+namespace {
+
+// Validates a segmented source description against `dim` and returns its device form (all zero = plain).
+int seg_src_from(const lx2v_kseg* kseg, int64_t ldx, int dim, const char* what, SegSrc& g) {
+  g = SegSrc{0, 0, 0, 0, 0, 0, 0};
+  if (kseg == nullptr) {
+    LX2V_REQUIRE(ldx >= dim, LX2V_EINVAL, "%s: row stride smaller than the row", what);
+    return LX2V_OK;
+  }
+  LX2V_REQUIRE(kseg->seg > 0 && kseg->seg % 8 == 0 && kseg->stride % 8 == 0 && ldx >= kseg->seg, LX2V_EINVAL, "%s: segments must be multiples of 8 columns, 8-aligned, inside a row", what);
+  const int64_t k1 = kseg->split > 0 ? kseg->split : dim;
+  LX2V_REQUIRE(k1 % kseg->seg == 0 && k1 <= dim, LX2V_EINVAL, "%s: region 1 (%lld columns) must hold whole segments of %lld", what, (long long)k1, (long long)kseg->seg);
+  if (kseg->split > 0) {
+    LX2V_REQUIRE(kseg->seg2 > 0 && kseg->seg2 % 8 == 0 && kseg->stride2 % 8 == 0 && kseg->base2 % 8 == 0 && kseg->lda2 % 8 == 0 && kseg->lda2 >= kseg->seg2 &&
+                     (dim - kseg->split) % kseg->seg2 == 0,
+                 LX2V_EINVAL, "%s: region 2 must hold whole, 8-aligned segments", what);
+  }
+  g = SegSrc{kseg->seg, kseg->stride, kseg->split, kseg->seg2, kseg->stride2, kseg->base2, kseg->lda2};
   return LX2V_OK;
 }
 
-extern "C" int lx2v_quant_int8_rowwise(const uint16_t* x, int64_t ldx, int8_t* out, int64_t ldo, float* scale, int64_t rows, int dim, int weight_mode, void* stream) {
-  LX2V_REQUIRE(rows == 0 || (x && out && scale), LX2V_EINVAL, "quant_int8: null tensor");
-  LX2V_REQUIRE(rows >= 0 && dim > 0 && dim % 8 == 0, LX2V_EINVAL, "quant_int8: dim=%d must be a positive multiple of 8", dim);
-  LX2V_REQUIRE(ldx % 8 == 0 && ldo % 8 == 0 && ldx >= dim && ldo >= dim, LX2V_EINVAL, "quant_int8: row strides must be multiples of 8 and >= dim");
-  LX2V_REQUIRE(lx2v_aligned16(x) && (reinterpret_cast<uintptr_t>(out) & 7u) == 0, LX2V_EINVAL, "quant_int8: x must be 16-byte, out 8-byte aligned");
+int quant_rows(bool int8, const uint16_t* x, int64_t ldx, const lx2v_kseg* kseg, void* out, int64_t ldo, float* scale, int64_t rows, int dim, int weight_mode, void* stream) {
+  const char* what = int8 ? "quant_int8" : "quant_fp8";
+  LX2V_REQUIRE(rows == 0 || (x && out && scale), LX2V_EINVAL, "%s: null tensor", what);
+  LX2V_REQUIRE(rows >= 0 && dim > 0 && dim % 8 == 0, LX2V_EINVAL, "%s: dim=%d must be a positive multiple of 8", what, dim);
+  LX2V_REQUIRE(ldx % 8 == 0 && ldo % 8 == 0 && ldo >= dim, LX2V_EINVAL, "%s: row strides must be multiples of 8, the output's >= dim", what);
+  LX2V_REQUIRE(lx2v_aligned16(x) && (reinterpret_cast<uintptr_t>(out) & 7u) == 0, LX2V_EINVAL, "%s: x must be 16-byte, out 8-byte aligned", what);
+  SegSrc g;
+  if (const int rc = seg_src_from(kseg, ldx, dim, what, g); rc != LX2V_OK) return rc;
   if (rows == 0) return LX2V_OK;
   const int nchunks = dim >> 3;
   int lpr = 64;
   if (nchunks <= 32 && (nchunks & (nchunks - 1)) == 0) lpr = nchunks;  // short rows share a wave
   const int64_t rows_per_block = 4 * (64 / lpr);
-  hipLaunchKernelGGL(quant_int8_rowwise_kernel, dim3((unsigned)((rows + rows_per_block - 1) / rows_per_block)), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo,
-                     scale, rows, dim, lpr, weight_mode != 0);
-  LX2V_CHECK_LAUNCH("quant_int8");
+  const dim3 grid((unsigned)((rows + rows_per_block - 1) / rows_per_block));
+  if (int8) hipLaunchKernelGGL(quant_int8_rowwise_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, g, (int8_t*)out, ldo, scale, rows, dim, lpr, weight_mode != 0);
+  else hipLaunchKernelGGL(quant_fp8_rowwise_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, g, (uint8_t*)out, ldo, scale, rows, dim, lpr);
+  LX2V_CHECK_LAUNCH(what);
   return LX2V_OK;
+}
+
+}  // namespace
+
+extern "C" int lx2v_quant_fp8_rowwise(const uint16_t* x, int64_t ldx, uint8_t* out, int64_t ldo, float* scale, int64_t rows, int dim, void* stream) {
+  return quant_rows(false, x, ldx, nullptr, out, ldo, scale, rows, dim, 0, stream);
+}
+
+extern "C" int lx2v_quant_fp8_rowwise_kseg(const uint16_t* x, int64_t ldx, const lx2v_kseg* kseg, uint8_t* out, int64_t ldo, float* scale, int64_t rows, int dim, void* stream) {
+  return quant_rows(false, x, ldx, kseg, out, ldo, scale, rows, dim, 0, stream);
+}
+
+extern "C" int lx2v_quant_int8_rowwise(const uint16_t* x, int64_t ldx, int8_t* out, int64_t ldo, float* scale, int64_t rows, int dim, int weight_mode, void* stream) {
+  return quant_rows(true, x, ldx, nullptr, out, ldo, scale, rows, dim, weight_mode, stream);
+}
+
+extern "C" int lx2v_quant_int8_rowwise_kseg(const uint16_t* x, int64_t ldx, const lx2v_kseg* kseg, int8_t* out, int64_t ldo, float* scale, int64_t rows, int dim, void* stream) {
+  return quant_rows(true, x, ldx, kseg, out, ldo, scale, rows, dim, 0, stream);
 }
 
 extern "C" int lx2v_dequant_fp8_rowwise(const uint8_t* q, int64_t ldq, const float* scale, uint16_t* out, int64_t ldo, int64_t rows, int dim, void* stream) {

@@ -53,9 +53,11 @@ _SIGNATURES = {
     "lx2v_set_option": [ctypes.c_char_p, _I],
     "lx2v_get_option": [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)],
     "lx2v_quant_fp8_rowwise": [_P, _I64, _P, _I64, _P, _I64, _I, _P],
+    "lx2v_quant_fp8_rowwise_kseg": [_P, _I64, _P, _P, _I64, _P, _I64, _I, _P],
     "lx2v_dequant_fp8_rowwise": [_P, _I64, _P, _P, _I64, _I64, _I, _P],
     "lx2v_gemm_fp8": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _P, _I64, _P, _P],
     "lx2v_quant_int8_rowwise": [_P, _I64, _P, _I64, _P, _I64, _I, _I, _P],
+    "lx2v_quant_int8_rowwise_kseg": [_P, _I64, _P, _P, _I64, _P, _I64, _I, _P],
     "lx2v_gemm_int8": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _P, _I64, _P, _P],
 }
 EXPORTS = tuple(_SIGNATURES) + ("lx2v_abi_version", "lx2v_last_error")
@@ -586,26 +588,41 @@ def cfg_combine(cond: torch.Tensor, uncond: torch.Tensor, guide_scale: float) ->
 
 
 # ------------------------------------------------------------------------------- fp8 W8A8
-def quant_fp8_rowwise(x: torch.Tensor):
-    """bf16 [rows, dim] -> (e4m3 [rows, dim] as torch.float8_e4m3fn, fp32 scale [rows]); x ~= q * scale."""
+def quant_fp8_rowwise(x: torch.Tensor, kseg: Optional["KSeg"] = None, dim: Optional[int] = None):
+    """bf16 [rows, dim] -> (e4m3 [rows, dim] as torch.float8_e4m3fn, fp32 scale [rows]); x ~= q * scale.
+    `kseg` + `dim`: x holds the rows of the first segment of a K-segmented operand (see KSeg) of `dim`
+    logical columns; the result is the plain matrix."""
     _need_bf16_cuda("quant_fp8.x", x)
-    rows, dim = x.shape
+    rows = x.shape[0]
+    dim = x.shape[1] if kseg is None else int(dim)
     q = torch.empty((rows, dim), dtype=torch.float8_e4m3fn, device=x.device)
     scale = torch.empty((rows,), dtype=torch.float32, device=x.device)
-    _check(load().lx2v_quant_fp8_rowwise(x.data_ptr(), x.stride(0), q.data_ptr(), q.stride(0), scale.data_ptr(), rows, dim, _stream()), "lx2v_quant_fp8_rowwise")
+    if kseg is None:
+        _check(load().lx2v_quant_fp8_rowwise(x.data_ptr(), x.stride(0), q.data_ptr(), q.stride(0), scale.data_ptr(), rows, dim, _stream()), "lx2v_quant_fp8_rowwise")
+    else:
+        _check(load().lx2v_quant_fp8_rowwise_kseg(x.data_ptr(), x.stride(0), ctypes.byref(kseg), q.data_ptr(), q.stride(0), scale.data_ptr(), rows, dim, _stream()),
+               "lx2v_quant_fp8_rowwise_kseg")
     return q, scale
 
 
-def quant_int8_rowwise(x: torch.Tensor, weight_mode: bool = False):
+def quant_int8_rowwise(x: torch.Tensor, weight_mode: bool = False, kseg: Optional["KSeg"] = None, dim: Optional[int] = None):
     """bf16 [rows, dim] -> (int8 [rows, dim], fp32 scale [rows]); x ~= q * scale.  `weight_mode`: the
     reference's per-channel weight quantiser (division by the scale, scale floor 1e-5 / 127) instead of
-    the per-token activation form (multiplication by 127 / max)."""
+    the per-token activation form (multiplication by 127 / max).  `kseg` + `dim` as in quant_fp8_rowwise
+    (activation form only)."""
     _need_bf16_cuda("quant_int8.x", x)
-    rows, dim = x.shape
+    rows = x.shape[0]
+    dim = x.shape[1] if kseg is None else int(dim)
     q = torch.empty((rows, dim), dtype=torch.int8, device=x.device)
     scale = torch.empty((rows,), dtype=torch.float32, device=x.device)
-    _check(load().lx2v_quant_int8_rowwise(x.data_ptr(), x.stride(0), q.data_ptr(), q.stride(0), scale.data_ptr(), rows, dim, int(bool(weight_mode)), _stream()),
-           "lx2v_quant_int8_rowwise")
+    if kseg is None:
+        _check(load().lx2v_quant_int8_rowwise(x.data_ptr(), x.stride(0), q.data_ptr(), q.stride(0), scale.data_ptr(), rows, dim, int(bool(weight_mode)), _stream()),
+               "lx2v_quant_int8_rowwise")
+    else:
+        if weight_mode:
+            raise Lx2vError("quant_int8: a segmented source is an activation; weight_mode does not apply")
+        _check(load().lx2v_quant_int8_rowwise_kseg(x.data_ptr(), x.stride(0), ctypes.byref(kseg), q.data_ptr(), q.stride(0), scale.data_ptr(), rows, dim, _stream()),
+               "lx2v_quant_int8_rowwise_kseg")
     return q, scale
 
 

@@ -214,8 +214,15 @@ class HunyuanVideo15TransformerInfer:
         self._branch_before_attn(ib, img, imod, qkv[:L], d, self.scheduler.cos_sin)
         self._branch_before_attn(tb, txt, tmod, qkv[L:], d, None)
         attn = self._infer_attn(weights, qkv, L, H, d)
-        self._branch_after_attn(ib, attn[:L], img, imod)
-        self._branch_after_attn(tb, attn[L:], txt, tmod)
+        if isinstance(attn, tuple):
+            # sequence parallel, fused runner: the image rows' result stays in the exchange's receive layout and the
+            # output projection (bf16 or W8A8) reads it as a K-segmented operand -- no gather copy
+            op, txt_attn = attn
+            self._branch_after_attn(ib, op.first, img, imod, kseg=op.kseg)
+            self._branch_after_attn(tb, txt_attn, txt, tmod)
+        else:
+            self._branch_after_attn(ib, attn[:L], img, imod)
+            self._branch_after_attn(tb, attn[L:], txt, tmod)
         return img.unsqueeze(0), txt.unsqueeze(0)
 
     @staticmethod
@@ -243,16 +250,21 @@ class HunyuanVideo15TransformerInfer:
         S = qkv.shape[0]
         q, k, v = (qkv[:, i * D:(i + 1) * D].unflatten(1, (H, d)) for i in range(3))
         if self.config["seq_parallel"]:
+            par = weights.self_attention_parallel
+            if self.fused_block and hasattr(par, "apply_segmented_joint") and getattr(weights.img_branch.part("attn_proj"), "supports_kseg", False) and S > img_len:
+                return par.apply_segmented_joint(q, k, v, img_len, attention_module=weights.self_attention, seq_p_group=self.seq_p_group,
+                                                 use_fp8_comm=self.seq_p_fp8_comm)
             cu = torch.tensor([0, S], dtype=torch.int32)
             return weights.self_attention_parallel.apply(q=q, k=k, v=v, img_qkv_len=img_len, cu_seqlens_qkv=cu, attention_module=weights.self_attention,
                                                          seq_p_group=self.seq_p_group, use_fp8_comm=self.seq_p_fp8_comm)
         return weights.self_attention.apply(q=q, k=k, v=v, cu_seqlens_q=None, cu_seqlens_kv=None, max_seqlen_q=S, max_seqlen_kv=S)
 
-    def _branch_after_attn(self, b, attn_rows, x, mod):
+    def _branch_after_attn(self, b, attn_rows, x, mod, kseg=None):
         """x += proj(attn) * gate1; x += fc2(gelu(fc1(modulate(LN(x))))) * gate2, in place
-        (transformer_infer.py:252-270)."""
+        (transformer_infer.py:252-270).  `kseg`: `attn_rows` are the rows of the first segment of a
+        K-segmented operand (fused runner only)."""
         if self.fused_block:
-            b.part("attn_proj").apply_residual_(attn_rows, x, mod[2])
+            b.part("attn_proj").apply_residual_(attn_rows, x, mod[2], kseg=kseg)
             h = b.part("mlp_fc1").apply_gelu(b.part("norm2").apply_modulate(x, mod[4], mod[3], quant_for=b.part("mlp_fc1")))
             b.part("mlp_fc2").apply_residual_(h, x, mod[5])
         else:

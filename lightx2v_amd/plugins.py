@@ -326,7 +326,7 @@ class HipFp8MMWeight(HipMMWeight):
     def load_state_dict(self, destination, block_index, adapter_block_index=None):
         raise NotImplementedError("hip-fp8: block-streamed (offload) loading is not built")
 
-    supports_kseg = False  # the activation is re-quantised row by row, which needs whole rows
+    supports_kseg = True  # the row-wise activation quantiser reads the segments and writes the plain e4m3 matrix
     accepts_quantized = True  # a producer that holds whole rows (LayerNorm) may hand over hip.QuantRows
 
     def adopt(self, weight_nk, bias, weight_scale=None):
@@ -348,8 +348,11 @@ class HipFp8MMWeight(HipMMWeight):
             o += n
         return out
 
-    def _run(self, x, epilogue, resid=None, gate=None, out=None):
-        xq, xs = (x.q, x.scale) if isinstance(x, hip.QuantRows) else hip.quant_fp8_rowwise(x)
+    def _run(self, x, epilogue, resid=None, gate=None, out=None, kseg=None):
+        if isinstance(x, hip.QuantRows):
+            xq, xs = x.q, x.scale
+        else:
+            xq, xs = hip.quant_fp8_rowwise(x, kseg=kseg, dim=self.weight_nk.shape[1])
         return hip.gemm_fp8(xq, xs, self.weight_nk, self.weight_scale, self.bias, epilogue=epilogue, resid=resid, gate=gate,
                             out=resid if epilogue == hip.EPI_RESIDUAL else out)
 
@@ -360,11 +363,12 @@ class HipFp8MMWeight(HipMMWeight):
         return self._run(input_tensor, hip.EPI_GELU_TANH)
 
     def apply_residual_(self, input_tensor, resid, gate=None, kseg=None):
-        if kseg is not None:
-            raise NotImplementedError("hip-fp8: K-segmented operands are built for the bf16 scheme only")
+        """`kseg`: `input_tensor` holds the rows of the first segment of a K-segmented operand (the
+        sequence-parallel attention result in its receive layout); the activation quantiser reads the
+        segments in place, so the gather copy of the bf16 path's alternative never happens."""
         if isinstance(gate, hip.RowMod) or resid.dtype == torch.float32:  # per-token gate / fp32 residual stream: product first, gated add as its own pass
-            return hip.gate_residual_(resid, self._run(input_tensor, hip.EPI_NONE), gate)
-        return self._run(input_tensor, hip.EPI_RESIDUAL, resid=resid, gate=gate)
+            return hip.gate_residual_(resid, self._run(input_tensor, hip.EPI_NONE, kseg=kseg), gate)
+        return self._run(input_tensor, hip.EPI_RESIDUAL, resid=resid, gate=gate, kseg=kseg)
 
 
 @MM_WEIGHT_REGISTER("hip-int8")
@@ -395,8 +399,8 @@ class HipInt8MMWeight(HipFp8MMWeight):
     def load_state_dict(self, destination, block_index, adapter_block_index=None):
         raise NotImplementedError("hip-int8: block-streamed (offload) loading is not built")
 
-    def _run(self, x, epilogue, resid=None, gate=None, out=None):
-        xq, xs = hip.quant_int8_rowwise(x)
+    def _run(self, x, epilogue, resid=None, gate=None, out=None, kseg=None):
+        xq, xs = hip.quant_int8_rowwise(x, kseg=kseg, dim=self.weight_nk.shape[1])
         return hip.gemm_int8(xq, xs, self.weight_nk, self.weight_scale, self.bias, epilogue=epilogue, resid=resid, gate=gate,
                              out=resid if epilogue == hip.EPI_RESIDUAL else out)
 

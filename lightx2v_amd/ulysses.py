@@ -303,6 +303,17 @@ class HipUlyssesAttnWeight(_AttnBase):
         return operand
 
 
+    def apply_segmented_joint(self, q, k, v, img_qkv_len, attention_module=None, seq_p_group=None, model_cls=None, use_fp8_comm=False):
+        """`apply_segmented` for the joint image + text layout (HunyuanVideo): rows [0, img_qkv_len) are this
+        rank's image shard, the rest text rows replicated on every rank.  Returns (operand, txt_out): the
+        image rows' result in its receive layout, the text rows' result [Lt, H*d] (None without text)."""
+        img_qkv_len = int(img_qkv_len)
+        if q.dim() == 4:
+            q, k, v = (t.reshape(-1, t.shape[-2], t.shape[-1]) for t in (q, k, v))
+        txt = None if q.shape[0] == img_qkv_len else tuple(t[img_qkv_len:] for t in (q, k, v))
+        return self._exchange_attend(q[:img_qkv_len], k[:img_qkv_len], v[:img_qkv_len], attention_module, seq_p_group, model_cls, txt, fp8=bool(use_fp8_comm))
+
+
 def make_groups(cfg_p_size: int, seq_p_size: int):
     """2-D layout (cfg_p, seq_p) with seq_p the fast (contiguous-rank) dimension, as
     lightx2v/utils/set_config.py:90-105 builds it.  Returns (cfg_index, seq_index, seq_group, cfg_group);

@@ -212,3 +212,35 @@ def test_fp8_block_is_unchanged_by_quantising_inside_the_layernorm(cuda, monkeyp
     separate = run()
     assert seen == ["Tensor"] * 3
     assert torch.equal(folded, separate)
+
+
+@pytest.mark.parametrize("widths,world", [([2], 2), ([3, 2], 2), ([1, 1, 1], 4), ([5], 1)])
+def test_rowwise_quantisers_read_a_segmented_source(cuda, widths, world):
+    """The sequence-parallel attention result in its receive layout (per head chunk [source rank][rows][w*d],
+    chunks of up to two widths) quantised row-wise straight from the segments: byte for byte and scale for
+    scale what quantising the gathered [rows, H*d] copy gives -- fp8 and int8 -- and the W8A8 output
+    projection fed with the segmented operand equals the one fed with the copy."""
+    from lightx2v_amd.ulysses import SegmentedOperand
+
+    sl, d = 37, 128
+    dim = world * sum(widths) * d
+    flat = _rand((sl * dim,), 500 + len(widths)).to(cuda)
+    op = SegmentedOperand(flat, sl, world, widths, d)
+    plain = op.gathered().contiguous()
+    assert plain.shape == (sl, dim)
+    for quant in (hip.quant_fp8_rowwise, hip.quant_int8_rowwise):
+        q_ref, s_ref = quant(plain)
+        q, s = quant(op.first, kseg=op.kseg, dim=dim)
+        assert torch.equal(s, s_ref)
+        assert torch.equal(q.view(torch.uint8), q_ref.view(torch.uint8))
+    for name in ("hip-fp8", "hip-int8"):
+        mm = L.MM_WEIGHT_REGISTER[name]("w.weight", "w.bias")
+        mm.load({"w.weight": _rand((256, dim), 77, 0.05).to(cuda), "w.bias": torch.randn(256, generator=torch.Generator().manual_seed(5)).to(cuda)})
+        assert mm.supports_kseg
+        x0 = _rand((sl, 256), 78).to(cuda)
+        a, b = x0.clone(), x0.clone()
+        mm.apply_residual_(plain, a, None)
+        mm.apply_residual_(op.first, b, None, kseg=op.kseg)
+        assert torch.equal(a, b)
+    with pytest.raises(hip.Lx2vError):
+        hip.quant_fp8_rowwise(op.first, kseg=op.kseg, dim=dim + 8)   # the segments do not tile this many columns
