@@ -313,6 +313,10 @@ int lx2v_quant_fp8_rowwise(const uint16_t* x, int64_t ldx, uint8_t* out, int64_t
  * plain [rows, dim] operand of lx2v_gemm_fp8, so the W8A8 output projection needs no gather copy either
  * (what the reference assembles with .contiguous() copies, lightx2v/common/ops/attn/utils/all2all.py:70-87,
  * before mm_weight.py:492-501 quantises it). */
+/* The same from fp32 rows: a checkpoint weight kept in fp32 (or widened from fp16) is quantised from its own values,
+ * as the reference does (`weight.to(torch.float32)` in front of the quantiser, mm_weight.py:312-320), not from a bf16 rounding of them. */
+int lx2v_quant_fp8_rowwise_f32(const float* x, int64_t ldx, uint8_t* out, int64_t ldo, float* scale,
+                               int64_t rows, int dim, void* stream);
 int lx2v_quant_fp8_rowwise_kseg(const uint16_t* x, int64_t ldx, const lx2v_kseg* kseg, uint8_t* out, int64_t ldo,
                                 float* scale, int64_t rows, int dim, void* stream);
 
@@ -344,6 +348,9 @@ int lx2v_gemm_fp8(const uint8_t* A, int64_t lda, const float* a_scale, const uin
  *   lightx2v/common/ops/mm/mm_weight.py:322-330, lightx2v/utils/quant_utils.py:39-49,85-92,111-113. */
 int lx2v_quant_int8_rowwise(const uint16_t* x, int64_t ldx, int8_t* out, int64_t ldo, float* scale,
                             int64_t rows, int dim, int weight_mode, void* stream);
+/* From fp32 rows (mm_weight.py:324-327 quantises `weight.to(torch.float32)`). */
+int lx2v_quant_int8_rowwise_f32(const float* x, int64_t ldx, int8_t* out, int64_t ldo, float* scale,
+                                int64_t rows, int dim, int weight_mode, void* stream);
 /* Activation form (weight_mode 0) from a segmented source, as lx2v_quant_fp8_rowwise_kseg. */
 int lx2v_quant_int8_rowwise_kseg(const uint16_t* x, int64_t ldx, const lx2v_kseg* kseg, int8_t* out, int64_t ldo,
                                  float* scale, int64_t rows, int dim, void* stream);

@@ -174,7 +174,18 @@ __global__ __launch_bounds__(256) void cfg_combine_kernel(float* out, const floa
 struct SegSrc {
   int64_t seg, stride, split, seg2, stride2, base2, lda2;
 };
-LX2V_DEVICE const uint16_t* seg_chunk(const uint16_t* x, int64_t ldx, const SegSrc& g, int64_t row, int col) {
+// Eight consecutive source elements as fp32: bf16 (one 16-byte chunk) or fp32 (two).
+LX2V_DEVICE void load8(const uint16_t* p, float (&f)[8]) { unpack8(*reinterpret_cast<const u32x4*>(p), f); }
+LX2V_DEVICE void load8(const float* p, float (&f)[8]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[i] = a[i];
+    f[4 + i] = b[i];
+  }
+}
+template <class T>
+LX2V_DEVICE const T* seg_chunk(const T* x, int64_t ldx, const SegSrc& g, int64_t row, int col) {
   if (g.seg == 0) return x + row * ldx + col;
   if (g.split == 0 || col < g.split) {
     const int64_t s = col / g.seg;
@@ -184,7 +195,8 @@ LX2V_DEVICE const uint16_t* seg_chunk(const uint16_t* x, int64_t ldx, const SegS
   return x + g.base2 + t * g.stride2 + row * g.lda2 + (c2 - t * g.seg2);
 }
 
-__global__ __launch_bounds__(256) void quant_fp8_rowwise_kernel(const uint16_t* __restrict__ x, int64_t ldx, const SegSrc src, uint8_t* __restrict__ out, int64_t ldo,
+template <class T>
+__global__ __launch_bounds__(256) void quant_fp8_rowwise_kernel(const T* __restrict__ x, int64_t ldx, const SegSrc src, uint8_t* __restrict__ out, int64_t ldo,
                                                                 float* __restrict__ scale, int64_t rows, int dim, int lpr) {
   const int lane = threadIdx.x & 63;
   const int l = lane & (lpr - 1);
@@ -194,7 +206,7 @@ __global__ __launch_bounds__(256) void quant_fp8_rowwise_kernel(const uint16_t* 
   float amax = 0.f;
   for (int ch = l; ch < nchunks; ch += lpr) {
     float f[8];
-    unpack8(*reinterpret_cast<const u32x4*>(seg_chunk(x, ldx, src, row, ch * 8)), f);
+    load8(seg_chunk(x, ldx, src, row, ch * 8), f);
 #pragma unroll
     for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(f[i]));
   }
@@ -205,7 +217,7 @@ __global__ __launch_bounds__(256) void quant_fp8_rowwise_kernel(const uint16_t* 
   uint8_t* orow = out + row * ldo;
   for (int ch = l; ch < nchunks; ch += lpr) {
     float f[8];
-    unpack8(*reinterpret_cast<const u32x4*>(seg_chunk(x, ldx, src, row, ch * 8)), f);
+    load8(seg_chunk(x, ldx, src, row, ch * 8), f);
     int lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, 0, false);
     lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, lo, true);
     int hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * inv, f[5] * inv, 0, false);
@@ -219,7 +231,8 @@ __global__ __launch_bounds__(256) void quant_fp8_rowwise_kernel(const uint16_t* 
 //     out = rint(x * (127 / max|x[r,:]|)); a row of zeros gets scale 0 and zeros.
 //   weight_mode 1 (weights; the reference's IntegerQuantizer(8, True, "per_channel"), lightx2v/utils/quant_utils.py:43-49,111-113):
 //     scale[r] = max(max|x[r,:]|, 1e-5) / 127, out = rint(x / scale[r]).
-__global__ __launch_bounds__(256) void quant_int8_rowwise_kernel(const uint16_t* __restrict__ x, int64_t ldx, const SegSrc src, int8_t* __restrict__ out, int64_t ldo,
+template <class T>
+__global__ __launch_bounds__(256) void quant_int8_rowwise_kernel(const T* __restrict__ x, int64_t ldx, const SegSrc src, int8_t* __restrict__ out, int64_t ldo,
                                                                  float* __restrict__ scale, int64_t rows, int dim, int lpr, int weight_mode) {
   const int lane = threadIdx.x & 63;
   const int l = lane & (lpr - 1);
@@ -229,7 +242,7 @@ __global__ __launch_bounds__(256) void quant_int8_rowwise_kernel(const uint16_t*
   float amax = 0.f;
   for (int ch = l; ch < nchunks; ch += lpr) {
     float f[8];
-    unpack8(*reinterpret_cast<const u32x4*>(seg_chunk(x, ldx, src, row, ch * 8)), f);
+    load8(seg_chunk(x, ldx, src, row, ch * 8), f);
 #pragma unroll
     for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(f[i]));
   }
@@ -240,7 +253,7 @@ __global__ __launch_bounds__(256) void quant_int8_rowwise_kernel(const uint16_t*
   int8_t* orow = out + row * ldo;
   for (int ch = l; ch < nchunks; ch += lpr) {
     float f[8];
-    unpack8(*reinterpret_cast<const u32x4*>(seg_chunk(x, ldx, src, row, ch * 8)), f);
+    load8(seg_chunk(x, ldx, src, row, ch * 8), f);
     uint32_t w[2] = {0u, 0u};
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -407,7 +420,8 @@ int seg_src_from(const lx2v_kseg* kseg, int64_t ldx, int dim, const char* what, 
   return LX2V_OK;
 }
 
-int quant_rows(bool int8, const uint16_t* x, int64_t ldx, const lx2v_kseg* kseg, void* out, int64_t ldo, float* scale, int64_t rows, int dim, int weight_mode, void* stream) {
+template <class T>
+int quant_rows(bool int8, const T* x, int64_t ldx, const lx2v_kseg* kseg, void* out, int64_t ldo, float* scale, int64_t rows, int dim, int weight_mode, void* stream) {
   const char* what = int8 ? "quant_int8" : "quant_fp8";
   LX2V_REQUIRE(rows == 0 || (x && out && scale), LX2V_EINVAL, "%s: null tensor", what);
   LX2V_REQUIRE(rows >= 0 && dim > 0 && dim % 8 == 0, LX2V_EINVAL, "%s: dim=%d must be a positive multiple of 8", what, dim);
@@ -421,8 +435,8 @@ int quant_rows(bool int8, const uint16_t* x, int64_t ldx, const lx2v_kseg* kseg,
   if (nchunks <= 32 && (nchunks & (nchunks - 1)) == 0) lpr = nchunks;  // short rows share a wave
   const int64_t rows_per_block = 4 * (64 / lpr);
   const dim3 grid((unsigned)((rows + rows_per_block - 1) / rows_per_block));
-  if (int8) hipLaunchKernelGGL(quant_int8_rowwise_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, g, (int8_t*)out, ldo, scale, rows, dim, lpr, weight_mode != 0);
-  else hipLaunchKernelGGL(quant_fp8_rowwise_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, g, (uint8_t*)out, ldo, scale, rows, dim, lpr);
+  if (int8) hipLaunchKernelGGL(quant_int8_rowwise_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, g, (int8_t*)out, ldo, scale, rows, dim, lpr, weight_mode != 0);
+  else hipLaunchKernelGGL(quant_fp8_rowwise_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, g, (uint8_t*)out, ldo, scale, rows, dim, lpr);
   LX2V_CHECK_LAUNCH(what);
   return LX2V_OK;
 }
@@ -438,6 +452,14 @@ extern "C" int lx2v_quant_fp8_rowwise_kseg(const uint16_t* x, int64_t ldx, const
 }
 
 extern "C" int lx2v_quant_int8_rowwise(const uint16_t* x, int64_t ldx, int8_t* out, int64_t ldo, float* scale, int64_t rows, int dim, int weight_mode, void* stream) {
+  return quant_rows(true, x, ldx, nullptr, out, ldo, scale, rows, dim, weight_mode, stream);
+}
+
+extern "C" int lx2v_quant_fp8_rowwise_f32(const float* x, int64_t ldx, uint8_t* out, int64_t ldo, float* scale, int64_t rows, int dim, void* stream) {
+  return quant_rows(false, x, ldx, nullptr, out, ldo, scale, rows, dim, 0, stream);
+}
+
+extern "C" int lx2v_quant_int8_rowwise_f32(const float* x, int64_t ldx, int8_t* out, int64_t ldo, float* scale, int64_t rows, int dim, int weight_mode, void* stream) {
   return quant_rows(true, x, ldx, nullptr, out, ldo, scale, rows, dim, weight_mode, stream);
 }
 

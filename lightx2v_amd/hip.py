@@ -54,6 +54,8 @@ _SIGNATURES = {
     "lx2v_get_option": [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)],
     "lx2v_quant_fp8_rowwise": [_P, _I64, _P, _I64, _P, _I64, _I, _P],
     "lx2v_quant_fp8_rowwise_kseg": [_P, _I64, _P, _P, _I64, _P, _I64, _I, _P],
+    "lx2v_quant_fp8_rowwise_f32": [_P, _I64, _P, _I64, _P, _I64, _I, _P],
+    "lx2v_quant_int8_rowwise_f32": [_P, _I64, _P, _I64, _P, _I64, _I, _I, _P],
     "lx2v_dequant_fp8_rowwise": [_P, _I64, _P, _P, _I64, _I64, _I, _P],
     "lx2v_gemm_fp8": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _P, _I64, _P, _P],
     "lx2v_quant_int8_rowwise": [_P, _I64, _P, _I64, _P, _I64, _I, _I, _P],
@@ -592,12 +594,19 @@ def quant_fp8_rowwise(x: torch.Tensor, kseg: Optional["KSeg"] = None, dim: Optio
     """bf16 [rows, dim] -> (e4m3 [rows, dim] as torch.float8_e4m3fn, fp32 scale [rows]); x ~= q * scale.
     `kseg` + `dim`: x holds the rows of the first segment of a K-segmented operand (see KSeg) of `dim`
     logical columns; the result is the plain matrix."""
-    _need_bf16_cuda("quant_fp8.x", x)
+    f32 = x.dtype == torch.float32 and kseg is None
+    if f32:
+        if not x.is_cuda or x.dim() != 2 or x.stride(1) != 1:
+            raise Lx2vError("quant_fp8.x: fp32 input must be a GPU matrix with a contiguous inner dimension")
+    else:
+        _need_bf16_cuda("quant_fp8.x", x)
     rows = x.shape[0]
     dim = x.shape[1] if kseg is None else int(dim)
     q = torch.empty((rows, dim), dtype=torch.float8_e4m3fn, device=x.device)
     scale = torch.empty((rows,), dtype=torch.float32, device=x.device)
-    if kseg is None:
+    if f32:
+        _check(load().lx2v_quant_fp8_rowwise_f32(x.data_ptr(), x.stride(0), q.data_ptr(), q.stride(0), scale.data_ptr(), rows, dim, _stream()), "lx2v_quant_fp8_rowwise_f32")
+    elif kseg is None:
         _check(load().lx2v_quant_fp8_rowwise(x.data_ptr(), x.stride(0), q.data_ptr(), q.stride(0), scale.data_ptr(), rows, dim, _stream()), "lx2v_quant_fp8_rowwise")
     else:
         _check(load().lx2v_quant_fp8_rowwise_kseg(x.data_ptr(), x.stride(0), ctypes.byref(kseg), q.data_ptr(), q.stride(0), scale.data_ptr(), rows, dim, _stream()),
@@ -610,12 +619,20 @@ def quant_int8_rowwise(x: torch.Tensor, weight_mode: bool = False, kseg: Optiona
     reference's per-channel weight quantiser (division by the scale, scale floor 1e-5 / 127) instead of
     the per-token activation form (multiplication by 127 / max).  `kseg` + `dim` as in quant_fp8_rowwise
     (activation form only)."""
-    _need_bf16_cuda("quant_int8.x", x)
+    f32 = x.dtype == torch.float32 and kseg is None
+    if f32:
+        if not x.is_cuda or x.dim() != 2 or x.stride(1) != 1:
+            raise Lx2vError("quant_int8.x: fp32 input must be a GPU matrix with a contiguous inner dimension")
+    else:
+        _need_bf16_cuda("quant_int8.x", x)
     rows = x.shape[0]
     dim = x.shape[1] if kseg is None else int(dim)
     q = torch.empty((rows, dim), dtype=torch.int8, device=x.device)
     scale = torch.empty((rows,), dtype=torch.float32, device=x.device)
-    if kseg is None:
+    if f32:
+        _check(load().lx2v_quant_int8_rowwise_f32(x.data_ptr(), x.stride(0), q.data_ptr(), q.stride(0), scale.data_ptr(), rows, dim, int(bool(weight_mode)), _stream()),
+               "lx2v_quant_int8_rowwise_f32")
+    elif kseg is None:
         _check(load().lx2v_quant_int8_rowwise(x.data_ptr(), x.stride(0), q.data_ptr(), q.stride(0), scale.data_ptr(), rows, dim, int(bool(weight_mode)), _stream()),
                "lx2v_quant_int8_rowwise")
     else:

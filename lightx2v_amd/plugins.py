@@ -305,7 +305,9 @@ class HipFp8MMWeight(HipMMWeight):
                 if not torch.cuda.is_available():
                     raise RuntimeError("hip-fp8: quantising a weight at load time runs on the GPU; no GPU is visible (no CPU fallback exists)")
                 w = w.cuda()
-            self.weight_nk, self.weight_scale = hip.quant_fp8_rowwise(w.to(COMPUTE_DTYPE).contiguous())
+            # quantised from the checkpoint's own values: fp32 (and fp16, widened) rows go in as fp32, like the
+            # reference's `weight.to(torch.float32)` in front of its quantiser (mm_weight.py:312-320)
+            self.weight_nk, self.weight_scale = hip.quant_fp8_rowwise((w if w.dtype == COMPUTE_DTYPE else w.to(torch.float32)).contiguous())
 
     def _calculate_size(self):
         return super()._calculate_size() + self.weight_scale.numel() * 4
@@ -394,7 +396,8 @@ class HipInt8MMWeight(HipFp8MMWeight):
                 if not torch.cuda.is_available():
                     raise RuntimeError("hip-int8: quantising a weight at load time runs on the GPU; no GPU is visible (no CPU fallback exists)")
                 w = w.cuda()
-            self.weight_nk, self.weight_scale = hip.quant_int8_rowwise(w.to(COMPUTE_DTYPE).contiguous(), weight_mode=True)
+            # from the checkpoint's own values (mm_weight.py:324-327 quantises `weight.to(torch.float32)`)
+            self.weight_nk, self.weight_scale = hip.quant_int8_rowwise((w if w.dtype == COMPUTE_DTYPE else w.to(torch.float32)).contiguous(), weight_mode=True)
 
     def load_state_dict(self, destination, block_index, adapter_block_index=None):
         raise NotImplementedError("hip-int8: block-streamed (offload) loading is not built")

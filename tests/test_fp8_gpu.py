@@ -244,3 +244,17 @@ def test_rowwise_quantisers_read_a_segmented_source(cuda, widths, world):
         assert torch.equal(a, b)
     with pytest.raises(hip.Lx2vError):
         hip.quant_fp8_rowwise(op.first, kseg=op.kseg, dim=dim + 8)   # the segments do not tile this many columns
+
+
+def test_fp8_weight_quantised_from_fp32_rows(cuda):
+    """An fp32 (or fp16) checkpoint weight goes into the load-time quantiser with its own values (the reference hands
+    its quantiser `weight.to(torch.float32)`, mm_weight.py:312-320): bit for bit the restated formula on fp32 input, and
+    not what a bf16 rounding in front would give."""
+    w = 0.02 * torch.randn(48, 384, generator=torch.Generator().manual_seed(12))
+    q_ref, s_ref = R.quant_fp8_rowwise(w)
+    q, s = hip.quant_fp8_rowwise(w.to(cuda))
+    assert torch.equal(s.cpu(), s_ref) and torch.equal(q.cpu().view(torch.uint8), q_ref.view(torch.uint8))
+    assert not torch.equal(R.quant_fp8_rowwise(w.to(torch.bfloat16))[1], s_ref)
+    mm = L.MM_WEIGHT_REGISTER["hip-fp8"]("w.weight", None)
+    mm.load({"w.weight": w.to(cuda)})
+    assert torch.equal(mm.weight_scale.cpu(), s_ref) and torch.equal(mm.weight_nk.cpu().view(torch.uint8), q_ref.view(torch.uint8))

@@ -26,6 +26,15 @@ def test_weight_quantiser_equals_the_references(cuda):
     mm = L.MM_WEIGHT_REGISTER["hip-int8"]("w.weight", None)
     mm.load({"w.weight": w.to(cuda)})                       # weight_auto_quant: quantised at load time
     assert torch.equal(mm.weight_nk.cpu(), torch.from_numpy(rec["q"])) and torch.equal(mm.weight_scale.cpu(), torch.from_numpy(rec["scale"]))
+    # an fp32 checkpoint weight is quantised from its own values, as the reference's `weight.to(torch.float32)` does
+    w32 = torch.from_numpy(rec["w_f32"])
+    q, s = hip.quant_int8_rowwise(w32.to(cuda), weight_mode=True)
+    assert torch.equal(q.cpu(), torch.from_numpy(rec["q_f32"])) and torch.equal(s.cpu(), torch.from_numpy(rec["scale_f32"]))
+    mm = L.MM_WEIGHT_REGISTER["hip-int8"]("w.weight", None)
+    mm.load({"w.weight": w32.to(cuda)})
+    assert torch.equal(mm.weight_nk.cpu(), torch.from_numpy(rec["q_f32"])) and torch.equal(mm.weight_scale.cpu(), torch.from_numpy(rec["scale_f32"]))
+    mm.load({"w.weight": w32.to(torch.float16).to(cuda)})   # fp16 is widened, not rounded to bf16
+    assert torch.equal(mm.weight_nk.cpu(), R.quant_int8_weight(w32.to(torch.float16))[0])
 
 
 @pytest.mark.parametrize("rows,dim", [(1, 128), (7, 256), (130, 1536), (33, 5120), (5, 13824), (9, 520), (1000, 128)])
