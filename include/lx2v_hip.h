@@ -180,6 +180,20 @@ int lx2v_attn_fwd_bf16(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_
                        int64_t sq, int64_t skv, int heads, int head_dim, float scale,
                        const float* rope_cos_sin, void* stream);
 
+/* The same call with room for partial results.  A launch of FEW heads over a long sequence (a head chunk of a
+ * sequence-parallel rank) is only a few rounds of one workgroup per CU long, and its last, partly filled round is a
+ * large share of it; with a workspace the launcher may split the KEYS of that round's query rows into ranges
+ * (shorter workgroups fill the round), leaving unnormalised partial outputs and (max, sum) pairs in `workspace`,
+ * and merge them in a second small kernel.  Same result up to the fp32 summation order of the merged rows.
+ * lx2v_attn_bf16_workspace_bytes gives the most a call of that shape uses (0: no split would be planned);
+ * `workspace` 16-byte aligned; a smaller or NULL workspace only limits the plan.  The library allocates nothing.
+ * No counterpart in the reference (flash-attn's num_splits heuristic lives inside the wheel). */
+int64_t lx2v_attn_bf16_workspace_bytes(int64_t sq, int64_t skv, int heads);
+int lx2v_attn_fwd_bf16_ws(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk,
+                          const uint16_t* v, int64_t ldv, uint16_t* out, int64_t ldo,
+                          int64_t sq, int64_t skv, int heads, int head_dim, float scale,
+                          const float* rope_cos_sin, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- Ulysses send-side pack: q,k,v [rows, heads*head_dim] -> [world][rows][3][heads/world*head_dim]
  * so ONE all-to-all moves q, k and v and the receiver sees a uniform token stride.
  * Replaces the three transpose().contiguous() packs of all2all_seq2head

@@ -20,6 +20,15 @@ struct AttnParams {
   int64_t ldq, ldk, ldv, ldo;
   int sq, skv, heads, nqb;
   float c;  // scale * log2(e)
+  // Key split (16x16x32 kernel only).  nparts > 1: workgroup ids run part-major over `nparts` copies of the
+  // (head, query block) grid, part j attends keys [j * part_keys, (j + 1) * part_keys) and leaves, instead of
+  // normalised bf16 rows, its unnormalised O (fp32 [nparts][heads][sq][128] at part_o) and per row the pair
+  // (m, l) (fp32 [nparts][heads][sq][2] at part_ml) for lx2v's merge kernel.
+  float* part_o = nullptr;
+  float* part_ml = nullptr;
+  int nparts = 1, part_keys = 0;
+  void* workspace = nullptr;       // launcher-side only: where a plan with a key split may put its partial results
+  int64_t workspace_bytes = 0;
 };
 
 LX2V_DEVICE int k_lds_off(int row, int ch) { return row * 256 + ((ch ^ (row & 15)) << 4); }

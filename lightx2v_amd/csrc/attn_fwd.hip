@@ -358,10 +358,24 @@ __global__ __launch_bounds__(NTHREADS) void attn_fwd_kernel(const AttnParams p) 
 int lx2v_attn_launch_w4(const lx2v_attn::AttnParams& p, hipStream_t st);   // attn_fwd_w4.hip
 int lx2v_attn_launch_x16(const lx2v_attn::AttnParams& p, hipStream_t st);  // attn_fwd_x16.hip
 
+int64_t lx2v_attn_x16_workspace_bytes(int64_t sq, int64_t skv, int heads);  // attn_fwd_x16.hip
+
+extern "C" int64_t lx2v_attn_bf16_workspace_bytes(int64_t sq, int64_t skv, int heads) {
+  if (sq <= 0 || skv <= 0 || heads <= 0 || sq >= (1LL << 31) || skv >= (1LL << 31) || lx2v_options().attn_kernel != 16) return 0;
+  return lx2v_attn_x16_workspace_bytes(sq, skv, heads);
+}
+
 extern "C" int lx2v_attn_fwd_bf16(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk,
                                   const uint16_t* v, int64_t ldv, uint16_t* out, int64_t ldo,
                                   int64_t sq, int64_t skv, int heads, int head_dim, float scale,
                                   const float* rope_cos_sin, void* stream) {
+  return lx2v_attn_fwd_bf16_ws(q, ldq, k, ldk, v, ldv, out, ldo, sq, skv, heads, head_dim, scale, rope_cos_sin, nullptr, 0, stream);
+}
+
+extern "C" int lx2v_attn_fwd_bf16_ws(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk,
+                                     const uint16_t* v, int64_t ldv, uint16_t* out, int64_t ldo,
+                                     int64_t sq, int64_t skv, int heads, int head_dim, float scale,
+                                     const float* rope_cos_sin, void* workspace, int64_t workspace_bytes, void* stream) {
   LX2V_REQUIRE(sq == 0 || (q && k && v && out), LX2V_EINVAL, "attn_fwd: null tensor");
   LX2V_REQUIRE(head_dim == HD, LX2V_EUNSUP, "attn_fwd: head_dim=%d, only 128 is built", head_dim);
   LX2V_REQUIRE(heads > 0 && sq >= 0 && skv >= 0, LX2V_EINVAL, "attn_fwd: bad shape sq=%lld skv=%lld heads=%d", (long long)sq, (long long)skv, heads);
@@ -382,6 +396,8 @@ extern "C" int lx2v_attn_fwd_bf16(const uint16_t* q, int64_t ldq, const uint16_t
   p.sq = (int)sq; p.skv = (int)skv; p.heads = heads;
   p.nqb = (int)((sq + QROWS - 1) / QROWS);
   p.c = scale * 1.4426950408889634f;
+  p.workspace = workspace;
+  p.workspace_bytes = workspace == nullptr ? 0 : workspace_bytes;
   const int64_t nwg = (int64_t)p.nqb * heads;
   LX2V_REQUIRE(nwg < (1LL << 31), LX2V_EUNSUP, "attn_fwd: grid too large");
   const dim3 grid((unsigned)nwg), block(NTHREADS);

@@ -74,8 +74,17 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
   const int wid = tid >> 6;
   const int c16 = lane & 15, g = lane >> 4;
 
-  const int qb_wg = blockIdx.x % p.nqb;
-  const int head = blockIdx.x / p.nqb;
+  // (key split: part-major copies of the (head, query block) grid, each over its own key range)
+  int bid = blockIdx.x, part = 0, key_base = 0, skv = p.skv;
+  if (p.nparts > 1) {
+    const int per = p.nqb * p.heads;
+    part = bid / per;
+    bid -= part * per;
+    key_base = part * p.part_keys;
+    skv = min(p.part_keys, p.skv - key_base);
+  }
+  const int qb_wg = bid % p.nqb;
+  const int head = bid / p.nqb;
   const int q0 = qb_wg * (64 * NQB) + wid * (16 * NQB);  // block qb covers rows q0 + 16 qb .. +15
 
   // ---- Q^T fragments, raw: lane holds Q[q0 + 16 qb + c][32 ks + 8 g .. +7] ----
@@ -104,8 +113,8 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
     d[3] = 0x00020000u;
     return d;
   };
-  const u32x4 k_rs = descriptor(p.k + head * HD, (int64_t)p.skv * p.ldk * 2);
-  const u32x4 v_rs = descriptor(p.v + head * HD, (int64_t)p.skv * p.ldv * 2);
+  const u32x4 k_rs = descriptor(p.k + (int64_t)key_base * p.ldk + head * HD, (int64_t)skv * p.ldk * 2);
+  const u32x4 v_rs = descriptor(p.v + (int64_t)key_base * p.ldv + head * HD, (int64_t)skv * p.ldv * 2);
   const int krow = 4 * wid + (lane >> 4);
   const int vrow = 8 * (wid >> 1) + ((lane >> 2) & 7);
   int k_vo[4], v_vo[4];  // piece i: 16 rows further
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
     for (int kb = 0; kb < 2; ++kb) s1[kb][qb] = f32x4{-1e30f, -1e30f, -1e30f, -1e30f};  // "half tile -1": every key masked
   }
 
-  const int nt = (p.skv + KVB - 1) / KVB;
+  const int nt = (skv + KVB - 1) / KVB;
 
   // S[kb][qb][i] of the half tile starting at key0 is key key0 + 8 g + 4 kb + i
   auto mask_half = [&](f32x4 (&sv)[2][NQB], int key0) __attribute__((always_inline)) {
@@ -215,7 +224,7 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        if (key0 + 8 * g + 4 * kb + i >= p.skv) {
+        if (key0 + 8 * g + 4 * kb + i >= skv) {
 #pragma unroll
           for (int qb = 0; qb < NQB; ++qb) sv[kb][qb][i] = -1e30f;
         }
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
     for (int qb = 0; qb < NQB; ++qb) ls[qb] = 0.f;
     float ea[NPAIR], eb[NPAIR];  // exps of pair p = (qb = p >> 2, j = p & 3): scores [j >> 1][qb][2 (j & 1)], + 1
     const int key0 = t * KVB + 32 * PAR;
-    if (__builtin_expect(key0 + 32 > p.skv, 0)) mask_half(Sc, key0);  // wave-uniform: only the last real half tile and the zero tiles (kept out of the fall-through path)
+    if (__builtin_expect(key0 + 32 > skv, 0)) mask_half(Sc, key0);  // wave-uniform: only the last real half tile and the zero tiles (kept out of the fall-through path)
     // DMA of this period: odd periods bring K(t+4) into the slot K(t) just left, even periods
     // V(t+2) into the slot V(t-2) left at the previous barrier; four pieces each, on even steps:
     // 0, 4, 8, 10 of the even periods (before their barrier, so that the count there is the same
@@ -480,8 +489,19 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
     float l = l_run[qb];
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
-    const float inv = 1.0f / l;
     const int qrow = q0 + 16 * qb + c16;
+    if (p.nparts > 1) {
+      // partial result of this key range: O as accumulated (relative to m), and (m, l) of the row
+      if (qrow < p.sq) {
+        const int64_t prow = ((int64_t)part * p.heads + head) * p.sq + qrow;
+        float* po = p.part_o + prow * HD + 4 * g;
+#pragma unroll
+        for (int db = 0; db < 8; ++db) *reinterpret_cast<f32x4*>(po + 16 * db) = o[qb][db];
+        if (g == 0) *reinterpret_cast<f32x2*>(p.part_ml + prow * 2) = f32x2{-negm[qb][0], l};
+      }
+      continue;
+    }
+    const float inv = 1.0f / l;
     if (qrow < p.sq) {
       uint16_t* op = p.out + (int64_t)qrow * p.ldo + head * HD + 4 * g;
 #pragma unroll
@@ -494,6 +514,35 @@ __global__ __launch_bounds__(X16_THREADS) void attn_fwd_x16_kernel(const AttnPar
 }
 
 }  // namespace
+
+// Merge of a key split: out[row, head] = sum_j 2^(m_j - M) O_j / sum_j 2^(m_j - M) l_j with M = max_j m_j (scores
+// are in log2 units).  One thread per (row, head, 4 channels).
+__global__ __launch_bounds__(256) void attn_merge_parts_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml, uint16_t* __restrict__ out,
+                                                               int64_t ldo, int sq, int heads, int nparts) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)sq * heads * 32;
+  if (idx >= total) return;
+  const int c4 = (int)(idx & 31);
+  const int64_t rh = idx >> 5;           // head-major, row-minor like the partial buffers
+  const int head = (int)(rh / sq);
+  const int row = (int)(rh - (int64_t)head * sq);
+  const int64_t stride = (int64_t)heads * sq;  // rows per part
+  float mx = -3.0e38f;
+  for (int j = 0; j < nparts; ++j) mx = fmaxf(mx, part_ml[(j * stride + rh) * 2]);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float lsum = 0.f;
+  for (int j = 0; j < nparts; ++j) {
+    const f32x2 ml = *reinterpret_cast<const f32x2*>(part_ml + (j * stride + rh) * 2);
+    const float w = __builtin_amdgcn_exp2f(ml[0] - mx);
+    const f32x4 oj = *reinterpret_cast<const f32x4*>(part_o + (j * stride + rh) * HD + 4 * c4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] += w * oj[i];
+    lsum += w * ml[1];
+  }
+  const float inv = 1.0f / lsum;
+  const u32x2 pk = {pack2(acc[0] * inv, acc[1] * inv), pack2(acc[2] * inv, acc[3] * inv)};
+  *reinterpret_cast<u32x2*>(out + (int64_t)row * ldo + head * HD + 4 * c4) = pk;
+}
 
 // Launch for p already validated by lx2v_attn_fwd_bf16 (no RoPE; K/V extent + 8 tiles < 4 GiB).
 // Query rows per workgroup = 4 waves x 16 NQB.  Five blocks per wave stream K/V a fifth less often
@@ -535,7 +584,17 @@ int launch_rows(const lx2v_attn::AttnParams& p, int64_t row0, int64_t row1, int 
 
 }  // namespace
 
-int lx2v_attn_launch_x16(const lx2v_attn::AttnParams& p, hipStream_t st) {
+namespace {
+
+struct Plan {
+  int m, t;            // blocks per wave of the main launch / of the second launch (0: none)
+  int64_t row0;        // first row of the second launch
+  bool last_head_only; // the second launch covers the last head only
+  int split;           // key ranges of the second launch (1: none)
+  double cost;
+};
+
+int device_cus() {
   static int cus_cached[64];
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
@@ -545,10 +604,19 @@ int lx2v_attn_launch_x16(const lx2v_attn::AttnParams& p, hipStream_t st) {
     }
     cus = cus_cached[dev];
   }
+  return cus;
+}
+
+// Bytes of partial results a key split of `rows` query rows of every head into `split` ranges needs.
+int64_t split_bytes(int64_t rows, int heads, int split) { return rows * heads * split * (int64_t)(HD + 2) * 4; }
+
+// The launch plan of a call.  Workgroups run in rounds of one per CU and a round costs in proportion to the
+// blocks per wave, so the choice goes by rounds x cost per round (units of "64 rows per wave": m blocks cost m,
+// 0.96 m for m = 5, about 1.3 for m = 1, whose workgroups spend relatively more on their prologue; a second
+// launch adds 0.15).  `max_split_bytes`: what a key split may use for its partial results (0: none).
+Plan make_plan(const lx2v_attn::AttnParams& p, int cus, int64_t max_split_bytes) {
   auto blocks = [&](int m) { return (int64_t)((p.sq + 64 * m - 1) / (64 * m)); };
   auto rounds = [&](int64_t wgs) { return (double)((wgs + cus - 1) / cus); };
-  // cost of one round in units of "64 rows per wave": m blocks cost m (0.96 m for m = 5, about 1.3
-  // for m = 1, whose workgroups spend relatively more on their prologue); a second launch adds 0.15
   auto per_round = [](int m) { return m == 5 ? 4.8 : m == 4 ? 4.0 : 1.3; };
   // the workgroups of a last round that is worth a launch of their own: few (one round of 64-row
   // workgroups takes their rows) and all of the last head
@@ -557,18 +625,13 @@ int lx2v_attn_launch_x16(const lx2v_attn::AttnParams& p, hipStream_t st) {
     return (wgs > cus && rest > 0 && rest <= blocks(m) && rest * m <= cus) ? rest : 0;
   };
   const bool tail_on = lx2v_options().attn_tail != 0;
-  struct Plan {
-    int m, t;            // blocks per wave of the main launch / of the second launch (0: none)
-    int64_t row0;        // first row of the second launch
-    bool last_head_only; // the second launch covers the last head only
-    double cost;
-  };
+  const int64_t ntiles = (p.skv + KVB - 1) / KVB;
   auto plan_for = [&](int m) {
     const int64_t nb = blocks(m), wgs = nb * p.heads;
-    Plan best{m, 0, p.sq, false, rounds(wgs) * per_round(m)};
+    Plan best{m, 0, p.sq, false, 1, rounds(wgs) * per_round(m)};
     if (!tail_on || wgs <= cus) return best;
     if (const int64_t rest = tail_of(m); rest > 0) {
-      const Plan c{m, 1, (nb - rest) * 64 * m, true, (double)(wgs / cus) * per_round(m) + 1.3};
+      const Plan c{m, 1, (nb - rest) * 64 * m, true, 1, (double)(wgs / cus) * per_round(m) + 1.3};
       if (c.cost < best.cost) best = c;
       return best;  // (the measured case: kept as it is)
     }
@@ -576,11 +639,24 @@ int lx2v_attn_launch_x16(const lx2v_attn::AttnParams& p, hipStream_t st) {
     const int64_t full = wgs / cus, nb_main = full * cus / p.heads;
     if (nb_main > 0 && nb_main < nb) {
       const int64_t row0 = nb_main * 64 * m, rest_rows = p.sq - row0;
+      const double main_cost = rounds(nb_main * p.heads) * per_round(m);
       for (int t : {4, 1}) {
         if (t == m) continue;
         const int64_t twgs = (rest_rows + 64 * t - 1) / (64 * t) * p.heads;
-        const Plan c{m, t, row0, false, rounds(nb_main * p.heads) * per_round(m) + rounds(twgs) * per_round(t) + 0.15};
+        const Plan c{m, t, row0, false, 1, main_cost + rounds(twgs) * per_round(t) + 0.15};
         if (c.cost < 0.99 * best.cost) best = c;
+      }
+      // ... and the same rows with their KEYS split into `sp` ranges: workgroups of 1 / sp the length fill the last
+      // round(s) more evenly than whole ones can (a launch of few heads is a few rounds long, and its last round
+      // is a large share of it).  Each range costs a prologue and a partial-result store of its own (0.08), the
+      // merge pass 0.1.
+      for (int t : {5, 4}) {
+        const int64_t twgs = (rest_rows + 64 * t - 1) / (64 * t) * p.heads;
+        for (int sp = 2; sp <= 8 && sp * 8 <= ntiles; ++sp) {
+          if (split_bytes(rest_rows, p.heads, sp) > max_split_bytes) break;
+          const Plan c{m, t, row0, false, sp, main_cost + rounds(twgs * sp) * (per_round(t) / sp + 0.08) + 0.1 + 0.15};
+          if (c.cost < 0.985 * best.cost) best = c;
+        }
       }
     }
     return best;
@@ -588,12 +664,31 @@ int lx2v_attn_launch_x16(const lx2v_attn::AttnParams& p, hipStream_t st) {
   Plan plan = plan_for(5);
   if (const Plan p4 = plan_for(4); p4.cost < plan.cost) plan = p4;
   if (lx2v_options().attn_qb != 0) plan = plan_for(lx2v_options().attn_qb);
+  return plan;
+}
+
+}  // namespace
+
+// Upper bound of the workspace a call of this shape can use (the plan is made without a limit).
+int64_t lx2v_attn_x16_workspace_bytes(int64_t sq, int64_t skv, int heads) {
+  lx2v_attn::AttnParams p{};
+  p.sq = (int)sq; p.skv = (int)skv; p.heads = heads;
+  const Plan plan = make_plan(p, device_cus(), INT64_MAX);
+  return plan.split > 1 ? (split_bytes(p.sq - plan.row0, heads, plan.split) + 255) / 256 * 256 : 0;
+}
+
+int lx2v_attn_launch_x16(const lx2v_attn::AttnParams& p, hipStream_t st) {
+  const int cus = device_cus();
+  const bool ws_ok = p.workspace != nullptr && (reinterpret_cast<uintptr_t>(p.workspace) & 15u) == 0;
+  const Plan plan = make_plan(p, cus, ws_ok ? p.workspace_bytes : 0);
+  auto blocks = [&](int m) { return (int64_t)((p.sq + 64 * m - 1) / (64 * m)); };
   if (plan.t == 0) return launch_rows(p, 0, p.sq, plan.m, false, st, "attn_fwd(x16)");
   if (plan.last_head_only) {
     // every head but the last in full, the last head up to row0; then the last head's remaining rows
     lx2v_attn::AttnParams pp = p;
     pp.nqb = (int)blocks(plan.m);
-    const int64_t nwg = (int64_t)pp.nqb * p.heads - tail_of(plan.m);
+    const int64_t wgs = (int64_t)pp.nqb * p.heads;
+    const int64_t nwg = wgs - wgs % cus;
     const int rc = plan.m == 5 ? launch_with_rounds(attn_fwd_x16_kernel<true, 5>, attn_fwd_x16_kernel<false, 5>, X16_THREADS, pp, nwg, st, "attn_fwd(x16)")
                                : launch_with_rounds(attn_fwd_x16_kernel<true, 4>, attn_fwd_x16_kernel<false, 4>, X16_THREADS, pp, nwg, st, "attn_fwd(x16)");
     if (rc != LX2V_OK) return rc;
@@ -601,5 +696,24 @@ int lx2v_attn_launch_x16(const lx2v_attn::AttnParams& p, hipStream_t st) {
   }
   const int rc = launch_rows(p, 0, plan.row0, plan.m, false, st, "attn_fwd(x16)");
   if (rc != LX2V_OK) return rc;
-  return launch_rows(p, plan.row0, p.sq, plan.t, false, st, "attn_fwd(x16 rows tail)");
+  if (plan.split == 1) return launch_rows(p, plan.row0, p.sq, plan.t, false, st, "attn_fwd(x16 rows tail)");
+  // rows [row0, sq) of every head, keys in `split` ranges of whole tiles -> partial results -> merge
+  lx2v_attn::AttnParams pp = p;
+  const int64_t rest_rows = p.sq - plan.row0;
+  const int64_t ntiles = (p.skv + KVB - 1) / KVB;
+  pp.q = p.q + plan.row0 * p.ldq;
+  pp.sq = (int)rest_rows;
+  pp.nqb = (int)((rest_rows + 64 * plan.t - 1) / (64 * plan.t));
+  pp.nparts = plan.split;
+  pp.part_keys = (int)((ntiles + plan.split - 1) / plan.split) * KVB;
+  pp.part_o = reinterpret_cast<float*>(p.workspace);
+  pp.part_ml = pp.part_o + rest_rows * p.heads * plan.split * HD;
+  const int64_t nwg = (int64_t)pp.nqb * p.heads * plan.split;
+  const int rc2 = plan.t == 5 ? launch_with_rounds(attn_fwd_x16_kernel<true, 5>, attn_fwd_x16_kernel<false, 5>, X16_THREADS, pp, nwg, st, "attn_fwd(x16 key split)")
+                              : launch_with_rounds(attn_fwd_x16_kernel<true, 4>, attn_fwd_x16_kernel<false, 4>, X16_THREADS, pp, nwg, st, "attn_fwd(x16 key split)");
+  if (rc2 != LX2V_OK) return rc2;
+  const int64_t threads = rest_rows * p.heads * 32;
+  hipLaunchKernelGGL(attn_merge_parts_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, pp.part_o, pp.part_ml, p.out + plan.row0 * p.ldo, p.ldo,
+                     (int)rest_rows, p.heads, plan.split);
+  return LX2V_OK;
 }

@@ -35,6 +35,8 @@ _SIGNATURES = {
     "lx2v_gelu_erf_bf16": [_P, _P, _I64, _P],
     "lx2v_gemm_bf16": [_P, _I64, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _I64, _I, _P, _I64, _P, _P],
     "lx2v_attn_fwd_bf16": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I, _I, _F, _P, _P],
+    "lx2v_attn_fwd_bf16_ws": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I, _I, _F, _P, _P, _I64, _P],
+    "lx2v_attn_bf16_workspace_bytes": [_I64, _I64, _I],
     "lx2v_ulysses_pack_qkv_bf16": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _I, _P],
     "lx2v_patchify_bf16": [_P, _P, _I64, _I, _I, _I, _I, _I, _P],
     "lx2v_unpatchify_f32": [_P, _I64, _P, _I, _I, _I, _I, _P],
@@ -84,7 +86,7 @@ def load() -> ctypes.CDLL:
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_int64 if name in ("lx2v_attn_fp8_workspace_bytes", "lx2v_attn_fp8_static_bytes") else ctypes.c_int
+        fn.restype = ctypes.c_int64 if name in ("lx2v_attn_fp8_workspace_bytes", "lx2v_attn_fp8_static_bytes", "lx2v_attn_bf16_workspace_bytes") else ctypes.c_int
     lib.lx2v_abi_version.restype = ctypes.c_int
     lib.lx2v_last_error.restype = ctypes.c_char_p
     _lib = lib
@@ -359,9 +361,16 @@ def gemm(a: torch.Tensor, w_out_in: torch.Tensor, bias=None, epilogue: int = EPI
     return out
 
 
+def attn_workspace_bytes(sq: int, skv: int, heads: int) -> int:
+    """Bytes of partial results `attn_fwd` can use for a call of this shape (0: its launch plan has no key split)."""
+    return int(load().lx2v_attn_bf16_workspace_bytes(int(sq), int(skv), int(heads)))
+
+
 def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional[float] = None,
-             rope_cos_sin: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """q [Sq,H,d], k/v [Skv,H,d] (token stride free, heads*d contiguous inside a token) -> [Sq, H*d]."""
+             rope_cos_sin: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q [Sq,H,d], k/v [Skv,H,d] (token stride free, heads*d contiguous inside a token) -> [Sq, H*d].
+    `workspace`: an optional uint8 GPU tensor for the partial results of a key split (launches of few heads over a
+    long sequence; `attn_workspace_bytes`); without it such launches run unsplit."""
     for n, t in (("q", q), ("k", k), ("v", v)):
         _need_bf16_cuda("attn." + n, t)
         if t.dim() != 3 or t.stride(1) != t.shape[2]:
@@ -379,9 +388,12 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional[
     if rope_cos_sin is not None:
         if rope_cos_sin.dtype != torch.float32 or not rope_cos_sin.is_contiguous() or tuple(rope_cos_sin.shape) != (sq, d):
             raise Lx2vError(f"attn: rope table must be contiguous fp32 [{sq}, {d}]")
-    st = load().lx2v_attn_fwd_bf16(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
-                                   out.data_ptr(), out.stride(0), sq, skv, H, d, float(scale), _ptr(rope_cos_sin), _stream())
-    _check(st, "lx2v_attn_fwd_bf16")
+    if workspace is not None and (not workspace.is_cuda or workspace.dtype != torch.uint8 or not workspace.is_contiguous()):
+        raise Lx2vError("attn: workspace must be a contiguous uint8 GPU tensor")
+    st = load().lx2v_attn_fwd_bf16_ws(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
+                                      out.data_ptr(), out.stride(0), sq, skv, H, d, float(scale), _ptr(rope_cos_sin),
+                                      _ptr(workspace), 0 if workspace is None else workspace.numel(), _stream())
+    _check(st, "lx2v_attn_fwd_bf16_ws")
     return out
 
 

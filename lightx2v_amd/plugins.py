@@ -101,9 +101,23 @@ class HipFlashAttnWeight(_AttnBase):
     Wan block uses: cu_seqlens = [0, S]).  `rope_cos_sin` (set by the caller before `apply`, fp32
     [S, d] cos||sin) makes the kernel rotate q and k on load; it is consumed by one call."""
 
+    _workspaces = {}   # per device: partial results of key-split launches, shared by every block (blocks run one after the other on one stream)
+
     def __init__(self):
         super().__init__()
         self.rope_cos_sin: Optional[torch.Tensor] = None
+
+    @classmethod
+    def _workspace_for(cls, q, k):
+        """A launch of few heads over a long sequence (a head chunk of a sequence-parallel rank) may split the keys
+        of its last round; the partial results live in one buffer per device that grows on demand."""
+        need = hip.attn_workspace_bytes(q.shape[0], k.shape[0], q.shape[1])
+        if need == 0:
+            return None
+        ws = cls._workspaces.get(q.device)
+        if ws is None or ws.numel() < need:
+            ws = cls._workspaces[q.device] = torch.empty(need, dtype=torch.uint8, device=q.device)
+        return ws
 
     def apply(self, q, k, v, drop_rate=0, attn_mask=None, causal=False, cu_seqlens_q=None, cu_seqlens_kv=None,
               max_seqlen_q=None, max_seqlen_kv=None, model_cls=None):
@@ -116,7 +130,7 @@ class HipFlashAttnWeight(_AttnBase):
         _one_sequence("hip_flash_attn", "cu_seqlens_q", cu_seqlens_q, max_seqlen_q, q.shape[0])
         _one_sequence("hip_flash_attn", "cu_seqlens_kv", cu_seqlens_kv, max_seqlen_kv, k.shape[0])
         rope, self.rope_cos_sin = self.rope_cos_sin, None
-        return hip.attn_fwd(q, k, v, rope_cos_sin=rope)
+        return hip.attn_fwd(q, k, v, rope_cos_sin=rope, workspace=None if rope is not None else self._workspace_for(q, k))
 
 
 @ATTN_WEIGHT_REGISTER("hip_fp8_attn")

@@ -131,3 +131,60 @@ def test_a_wave_held_back_behind_the_tile_barrier_changes_nothing(case, options)
     assert st == 0, lag.lx2v_last_error()
     torch.cuda.synchronize()
     assert torch.equal(got, want)
+
+
+def test_no_key_split_where_the_row_split_already_fills_the_last_round(case, options):
+    """3 heads x 75 600 rows: two full rounds of 320-row workgroups, then 249 workgroups of 256 rows -- 97 % of a round.
+    No key split pays there, and the workspace query says so."""
+    q, k, v, _, _ = case
+    options(attn_kernel=16, attn_qb=0, attn_tail=1)
+    assert hip.attn_workspace_bytes(S, S, 3) == 0
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device=q.device)
+    assert torch.equal(hip.attn_fwd(q[:, :3], k[:, :3], v[:, :3], workspace=ws), hip.attn_fwd(q[:, :3], k[:, :3], v[:, :3]))
+
+
+@pytest.mark.parametrize("heads", [5, 2])
+def test_key_split_of_the_last_round_of_a_launch_with_few_heads(case, options, heads):
+    """Head chunks of a sequence-parallel rank (5 heads: Wan-14B at seq_p = 4 in two chunks; 2: the narrow chunk at seq_p = 8) are a
+    few rounds of one workgroup per CU long.  Given a workspace, the launch plan splits the KEYS of the last round's
+    query rows into ranges, whose partial results a merge kernel combines: the rows of the full rounds are computed
+    exactly as without it, the merged rows agree up to the summation order, and both match the CPU oracle."""
+    import time
+
+    q, k, v, rows, ref = case
+    qh, kh, vh = q[:, :heads], k[:, :heads], v[:, :heads]
+    options(attn_kernel=16, attn_qb=0, attn_tail=1)
+    need = hip.attn_workspace_bytes(S, S, heads)
+    assert need > 0, "the plan for this shape should hold a key split"
+    ws = torch.empty(need, dtype=torch.uint8, device=q.device)
+    plain = hip.attn_fwd(qh, kh, vh)
+    split = hip.attn_fwd(qh, kh, vh, workspace=ws)
+    assert torch.equal(hip.attn_fwd(qh, kh, vh, workspace=ws), split)     # deterministic
+    differ = (plain != split).any(dim=1).nonzero().flatten()
+    assert differ.numel() > 0                                              # the split is live
+    row0 = int(differ.min())
+    if heads == 5:
+        # both plans run four full rounds of 320-row workgroups first: those rows are the same arithmetic
+        assert row0 == 204 * 320 and torch.equal(plain[:row0], split[:row0])
+    # (2 heads: without a workspace the cheaper plan has 256-row workgroups, with it 320-row ones and a key split --
+    # other rescale points in every row, the last bf16 bit of a few outputs)
+    assert (plain.float() - split.float()).abs().max().item() <= 2e-3
+    tail0 = 204 * 320 if heads == 5 else 128 * 320   # first row of the key-split launch
+    pick = torch.cat([rows, torch.tensor([tail0 - 1, tail0, tail0 + 1, tail0 + 319, tail0 + 320, S - 1])]).unique()
+    want = R.sdpa(qh[pick.to(q.device)].float().cpu(), kh.float().cpu(), vh.float().cpu())
+    got = split[pick.to(split.device)].float().cpu()
+    assert cos(got, want) >= 0.9999
+    assert torch.nn.functional.cosine_similarity(got, want, dim=1).min().item() >= 0.999
+    # a workspace that is too small only limits the plan
+    small = hip.attn_fwd(qh, kh, vh, workspace=ws[:4096])
+    assert torch.equal(small, plain)
+    t = {}
+    for name, w in (("plain", None), ("split", ws)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            hip.attn_fwd(qh, kh, vh, workspace=w)
+        torch.cuda.synchronize()
+        t[name] = (time.perf_counter() - t0) / 5 * 1e3
+    fl = 4.0 * S * S * heads * D
+    print(f"\n{heads} heads x {S} rows: rows split {t['plain']:.2f} ms ({fl / t['plain'] * 1e-9:.0f} TFLOP/s), with key split {t['split']:.2f} ms ({fl / t['split'] * 1e-9:.0f} TFLOP/s)")
