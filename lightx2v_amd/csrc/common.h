@@ -49,7 +49,9 @@ LX2V_DEVICE float wave_sum(float v) {
 }
 
 LX2V_DEVICE float gelu_tanh(float x) {
-  // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) written as x * sigmoid(2u)
+  // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) written as x * sigmoid(2u); evaluated as written
+  // (no re-association under -ffast-math), so that every kernel with this epilogue rounds alike
+#pragma clang fp reassociate(off)
   const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
   return x / (1.0f + __expf(-2.0f * u));
 }

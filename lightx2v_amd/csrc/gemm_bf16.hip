@@ -474,7 +474,7 @@ extern "C" int lx2v_gemm_bf16(const uint16_t* A, int64_t lda, const lx2v_kseg* k
   // Kernel choice (option gemm_kernel): 0 = the persistent one-wave-per-SIMD kernel, 1 = 8 waves with
   // one barrier per K-tile, 2 = 8 waves in the ping-pong schedule.  All three give identical results.
   const int which = lx2v_options().gemm_kernel;
-  if (which == 0 && p.a_bytes < (1LL << 32) && p.w_bytes < (1LL << 32)) {
+  if (which == 0 && p.a_bytes < (1LL << 32) && p.w_bytes < (1LL << 32) && ldc < (1LL << 22)) {  // (its stores address one 256-row panel of C with 31 bits)
     const int rc = lx2v_gemm_launch_w4(p, epilogue, st);
     if (rc != LX2V_OK) return rc;
     LX2V_CHECK_LAUNCH("gemm(persistent)");

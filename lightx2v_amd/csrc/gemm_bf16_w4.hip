@@ -274,9 +274,9 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_bf16_w4_kernel(const GemmPara
   };
   // AFTER_EPI: the barrier of the first K-tile behind an epilogue.  The epilogue's 32 stores are
   // younger than the half-tile that has to have landed and older than the 8 DMA instructions just
-  // issued; memory operations retire in order, so 40 may stay outstanding.  (Only behind an
-  // interior tile: at the M / N edge a wave issues fewer stores, and the count would reach back
-  // into the DMA that has to be complete.)
+  // issued; memory operations retire in order, so 40 may stay outstanding.  (Every epilogue issues
+  // all 32: the stores of rows and columns outside C are dropped by the range check of their
+  // buffer descriptor, not branched around.)
   auto sync_x = [&](auto AFTER_EPIc) __attribute__((always_inline)) {
     if constexpr (W4_ABL & 4) return;
     if constexpr (!(W4_ABL & 64)) {
@@ -303,6 +303,19 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_bf16_w4_kernel(const GemmPara
     for (int nt = 0; nt < 8; ++nt) waddr[nt] = stg + fr * 512 + (((nt * 4 + fq) ^ fr) << 4);
     const int gn = n0 + wn * 128 + fr * 8;  // this lane's eight output columns
     const bool col_ok = gn < p.N;           // N % 8 == 0: all eight or none
+    // Stores go through a raw buffer descriptor of the tile's row panel: rows past M lie beyond its range and lanes
+    // whose columns lie past N get an offset beyond it, and the hardware drops such stores -- no branch around a
+    // store, so every pass issues the same memory operations and the waits the compiler places between them
+    // (memory operations retire in order) are exact counts instead of worst cases over skipped stores.
+    const __amdgpu_buffer_rsrc_t c_rs = [&]() __attribute__((always_inline)) {
+      const uint64_t a = reinterpret_cast<uint64_t>(p.C + (int64_t)m0 * p.ldc);
+      const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));  // (the builtin returns int)
+      void* pb = reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+      const int rows = min(p.M - m0, 256);  // the panel's rows inside C (the launcher keeps 256 rows of C below 2 GiB)
+      return __builtin_amdgcn_make_buffer_rsrc(pb, 0, __builtin_amdgcn_readfirstlane(rows * p.ldc * 2), 0x00020000);
+    }();
+    const int c_col = gn * 2;  // byte offset of the lane's columns inside a row
+    constexpr int C_NOWHERE = (int)0x80000000u;  // an offset at or past the end of any such range
     float bv[8], gv[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -329,31 +342,40 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_bf16_w4_kernel(const GemmPara
     // (vmcnt(0)) in front of every one of them, i.e. for the previous store's completion.
 #pragma unroll
     for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(bv[j]), "+v"(gv[j]));
-    // Residual rows are loaded one pass ahead (clamped addresses, no branch: the only conditional
-    // operation of a pass is the store), so that no pass waits for its own loads -- a wait for the
-    // newest load would also wait for every store before it.
-    u32x4 res[2][4];
-    auto load_resid = [&](int mt, u32x4 (&dst)[4]) __attribute__((always_inline)) {
-      if constexpr (EPI == LX2V_EPI_RESIDUAL) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
+    // Residual rows are loaded THREE passes ahead (clamped addresses, no branch: the only conditional operation
+    // of a pass is the store).  Memory operations retire in order, so a pass that waits for its residual rows also
+    // waits for every store issued before their loads; one pass ahead that was the previous pass's stores, a full
+    // write latency per pass.  The ring of four passes (16 registers each) lives in the fragment variables of
+    // K-step 1, which are dead between K-tiles: what they hold when the epilogue ends is complete, consumed data.
+    auto resbuf = [&](auto bc, auto itc) __attribute__((always_inline)) -> u32x4& {
+      constexpr int b = decltype(bc)::value, it = decltype(itc)::value;
+      if constexpr (b < 2) return f1.a[(b & 1) * 4 + it];
+      else return f1.w[(b & 1) * 4 + it];
+    };
+    auto load_resid = [&](auto mtc) __attribute__((always_inline)) {
+      constexpr int mt = decltype(mtc)::value;
+      if constexpr (EPI == LX2V_EPI_RESIDUAL && mt < 8) {
+        static_for<0, 4>([&](auto itc) __attribute__((always_inline)) {
+          constexpr int it = decltype(itc)::value;
           const int gm = min(m0 + wm * 128 + mt * 16 + it * 4 + fq, p.M - 1);
-          dst[it] = *reinterpret_cast<const u32x4*>(p.resid + (int64_t)gm * p.ldr + (col_ok ? gn : 0));
-        }
+          resbuf(IntC<mt & 3>{}, itc) = *reinterpret_cast<const u32x4*>(p.resid + (int64_t)gm * p.ldr + (col_ok ? gn : 0));
+        });
       }
     };
-    load_resid(0, res[0]);
+    load_resid(IntC<0>{});
+    load_resid(IntC<1>{});
+    load_resid(IntC<2>{});
     static_for<0, 8>([&](auto mtc) __attribute__((always_inline)) {
       constexpr int mt = decltype(mtc)::value;
-      if constexpr (mt + 1 < 8) load_resid(mt + 1, res[(mt + 1) & 1]);
+      load_resid(IntC<mt + 3>{});
       static_for<0, 8>([&](auto ntc) __attribute__((always_inline)) {
         constexpr int nt = decltype(ntc)::value;
         acc_to_lds<acc_in_agpr(nt, mt)>(waddr[nt], acc[nt][mt]);
       });
       // (one wave's LDS instructions execute in order: the reads below see the writes above, and
       // the next pass's writes come after these reads)
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
+      static_for<0, 4>([&](auto itc) __attribute__((always_inline)) {
+        constexpr int it = decltype(itc)::value;
         const int r = it * 4 + fq;
         const int gm = m0 + wm * 128 + mt * 16 + r;
         const char* row = lds + epi_base + wid * 8192 + r * 512;
@@ -370,14 +392,14 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_bf16_w4_kernel(const GemmPara
         }
         if (EPI == LX2V_EPI_RESIDUAL) {
           float y[8];
-          unpack8(res[mt & 1][it], y);
+          unpack8(resbuf(IntC<mt & 3>{}, itc), y);
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = (float)(__bf16)v[j] + y[j];  // the product is rounded to bf16 before the add, as in the 8-wave kernels
         }
         const u32x4 out = pack8(v);
         if constexpr (W4_ABL & 512) asm volatile("" ::"v"(out));
-        else if (gm < p.M && col_ok) *reinterpret_cast<u32x4*>(p.C + (int64_t)gm * p.ldc + gn) = out;
-      }
+        else __builtin_amdgcn_raw_buffer_store_b128(out, c_rs, col_ok ? (int)((int64_t)(gm - m0) * p.ldc * 2) + c_col : C_NOWHERE, 0, 0);
+      });
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -405,7 +427,7 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_bf16_w4_kernel(const GemmPara
 
   // ---- the stream ----
   int ord = 0, kt = 0;  // output tile ordinal and K-tile of stream position j
-  bool relaxed = false; // the previous K-tile ended in the epilogue of an interior tile (32 stores per wave)
+  bool relaxed = false; // the previous K-tile ended in an epilogue (32 stores per wave)
   int r5 = 0;           // (2 j) % 5: slot of A(j); W(j) r5 + 1, A(j+1) r5 + 2, W(j+1) r5 + 3, free r5 + 4 (all mod 5)
   auto slot = [&](int k) __attribute__((always_inline)) -> int {  // byte offset of slot (r5 + k) % 5
     const int s5 = r5 + k;
@@ -430,7 +452,7 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_bf16_w4_kernel(const GemmPara
     if (++kt == nk) {
       int m0, n0;
       tile_origin(p, ord * grid + (int)blockIdx.x, m0, n0);
-      relaxed = m0 + BM <= p.M && n0 + BN <= p.N;
+      relaxed = !(W4_ABL & (8 | 512));
       if constexpr (!(W4_ABL & 8)) {
         epilogue(m0, n0, sw);  // W(j)'s slot is idle until A(j + 3) is staged into it, in the next step 0 ...
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

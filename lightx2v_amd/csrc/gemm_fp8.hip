@@ -41,7 +41,7 @@ LX2V_DEVICE void gemm_fp8_epilogue(const GemmParams& p, f32x4 (&acc)[4][8], char
       const float sa = p.a_scale[min(m0 + wm * 128 + mt * 16 + fr, p.M - 1)];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        v[j] = acc[nt][mt][j] * sa * sw[j] + bv[j];
+        v[j] = dequant_bias(acc[nt][mt][j], sa, sw[j], bv[j]);
         if (EPI == LX2V_EPI_GELU_TANH) v[j] = gelu_tanh(v[j]);
         if (EPI == LX2V_EPI_RESIDUAL) v[j] *= gv[j];
       }
@@ -410,7 +410,7 @@ static int gemm_w8a8(bool int8, const uint8_t* A, int64_t lda, const float* a_sc
   if (int8) LX2V_REQUIRE(K <= 131072, LX2V_EUNSUP, "gemm_int8: K=%lld: the int32 accumulators hold 127 * 127 * K up to K = 131072", (long long)K);
   // Default (gemm_kernel = 0): the persistent one-wave-per-SIMD kernel.  Its staging addresses rows through
   // 32-bit buffer offsets, so operands whose extent reaches 4 GiB stay with the 8-wave kernels.
-  if (lx2v_options().gemm_kernel == 0 && M * lda < (1LL << 32) && N * ldw < (1LL << 32)) {
+  if (lx2v_options().gemm_kernel == 0 && M * lda < (1LL << 32) && N * ldw < (1LL << 32) && ldc < (1LL << 22)) {  // (its stores address one 256-row panel of C with 31 bits)
     const int rc = lx2v_gemm_w8a8_launch_w4(p, int8, epilogue, st);
     if (rc != LX2V_OK) return rc;
     LX2V_CHECK_LAUNCH(int8 ? "gemm_int8(w4)" : "gemm_fp8(w4)");

@@ -48,6 +48,15 @@ LX2V_DEVICE void glds16(const void* g, void* l) {
 }
 
 // Bijective remap so that blocks sharing an XCD (same blockIdx % 8) get a contiguous run of tiles.
+// Dequantise one sum and add the bias: (v * sa) * sw + b, the last step fused, in exactly this association.  Every
+// W8A8 kernel goes through here so that the schedules agree bit for bit; under -ffast-math the plain expression
+// is re-associated differently from one kernel (and one build) to the next.
+LX2V_DEVICE float dequant_bias(float v, float sa, float sw, float b) {
+#pragma clang fp reassociate(off) contract(off)
+  const float t = v * sa;
+  return __builtin_fmaf(t, sw, b);
+}
+
 LX2V_DEVICE int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
   const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;

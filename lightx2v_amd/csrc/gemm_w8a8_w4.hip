@@ -258,8 +258,9 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_w8a8_w4_kernel(const GemmPara
     });
     // ---- X: this wave's DMA except the 8 pieces just issued has landed, its reads of W(j) are done;
     // behind the barrier that holds for every wave (K-tile j + 1 complete, W(j) and A(j) released).
-    // `relaxed`: the previous K-tile ended in the epilogue of an interior tile, whose memory operations
-    // (at least the 32 stores) are younger than the data waited for: 40 may stay outstanding.
+    // `relaxed`: the previous K-tile ended in an epilogue, whose 32 stores (issued for every row and column of the
+    // tile; those outside C are dropped by the range check of their descriptor) are younger than the data waited
+    // for: 40 may stay outstanding.
     if constexpr (!(W8_ABL & 4)) {
       if (relaxed) asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
@@ -321,6 +322,19 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_w8a8_w4_kernel(const GemmPara
     for (int nt = 0; nt < 8; ++nt) waddr[nt] = stg + fr * 512 + (((nt * 4 + fq) ^ fr) << 4);
     const int gn = n0 + wn * 128 + fr * 8;  // this lane's eight output columns
     const bool col_ok = gn < p.N;           // N % 8 == 0: all eight or none
+    // Stores go through a raw buffer descriptor of the tile's row panel: rows past M lie beyond its range and lanes
+    // whose columns lie past N get an offset beyond it, and the hardware drops such stores -- no branch around a
+    // store, so every pass issues the same memory operations and the waits the compiler places between them
+    // (memory operations retire in order) are exact counts instead of worst cases over skipped stores.
+    const __amdgpu_buffer_rsrc_t c_rs = [&]() __attribute__((always_inline)) {
+      const uint64_t a = reinterpret_cast<uint64_t>(p.C + (int64_t)m0 * p.ldc);
+      const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));  // (the builtin returns int)
+      void* pb = reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+      const int rows = min(p.M - m0, 256);  // the panel's rows inside C (the launcher keeps 256 rows of C below 2 GiB)
+      return __builtin_amdgcn_make_buffer_rsrc(pb, 0, __builtin_amdgcn_readfirstlane(rows * p.ldc * 2), 0x00020000);
+    }();
+    const int c_col = gn * 2;  // byte offset of the lane's columns inside a row
+    constexpr int C_NOWHERE = (int)0x80000000u;  // an offset at or past the end of any such range
     float bv[8], gv[8], swv[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -354,28 +368,32 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_w8a8_w4_kernel(const GemmPara
     for (int h = 0; h < 2; ++h) sa_lane[h] = p.a_scale[min(m0 + wm * 128 + 64 * h + lane, p.M - 1)];
 #pragma unroll
     for (int h = 0; h < 2; ++h) asm volatile("" : "+v"(sa_lane[h]));
-    // Residual rows are loaded one pass ahead (clamped addresses, no branch: the only conditional
-    // operation of a pass is the store).  They live in W fragment variables that are dead between
-    // K-tiles (fw[2..5]: two passes of four 16-byte rows), so the epilogue needs no registers of its
-    // own for them; what those variables hold when the epilogue ends is complete, consumed data.
-    auto load_rows = [&](int mt, Frag8& d0, Frag8& d1) __attribute__((always_inline)) {
-      if constexpr (EPI == LX2V_EPI_RESIDUAL) {
+    // Residual rows are loaded TWO passes ahead (clamped addresses, no branch: the only conditional operation of a
+    // pass is the store).  Memory operations retire in order, so a pass that waits for its residual rows also waits
+    // for every store issued before their loads; one pass ahead that was the previous pass's stores, a full write
+    // latency per pass.  The ring of three passes (four 16-byte rows each) lives in W fragment variables that are
+    // dead between K-tiles (fw[2..7]); what they hold when the epilogue ends is complete, consumed data.
+    auto load_rows = [&](auto mtc) __attribute__((always_inline)) {
+      constexpr int mt = decltype(mtc)::value;
+      if constexpr (EPI == LX2V_EPI_RESIDUAL && mt < 8) {
         i32x4 r[4];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           const int gm = min(m0 + wm * 128 + mt * 16 + it * 4 + fq, p.M - 1);
           r[it] = *reinterpret_cast<const i32x4*>(p.resid + (int64_t)gm * p.ldr + (col_ok ? gn : 0));
         }
+        Frag8 &d0 = fw[2 + 2 * (mt % 3)], &d1 = fw[3 + 2 * (mt % 3)];
         d0.lo = r[0];
         d0.hi = r[1];
         d1.lo = r[2];
         d1.hi = r[3];
       }
     };
-    load_rows(0, fw[2], fw[3]);
+    load_rows(IntC<0>{});
+    load_rows(IntC<1>{});
     static_for<0, 8>([&](auto mtc) __attribute__((always_inline)) {
       constexpr int mt = decltype(mtc)::value;
-      if constexpr (mt + 1 < 8) load_rows(mt + 1, fw[2 + 2 * ((mt + 1) & 1)], fw[3 + 2 * ((mt + 1) & 1)]);
+      load_rows(IntC<mt + 2>{});
       static_for<0, 8>([&](auto ntc) __attribute__((always_inline)) {
         constexpr int nt = decltype(ntc)::value;
         acc_to_lds<acc_in_agpr(nt, mt)>(waddr[nt], acc[nt][mt]);
@@ -397,20 +415,20 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_w8a8_w4_kernel(const GemmPara
         const float sa = __shfl(sa_lane[mt >> 2], (mt & 3) * 16 + r, 64);  // row mt * 16 + r of the corner
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          v[j] = v[j] * sa * swv[j] + bv[j];
+          v[j] = dequant_bias(v[j], sa, swv[j], bv[j]);
           if (EPI == LX2V_EPI_GELU_TANH) v[j] = gelu_tanh(v[j]);
           if (EPI == LX2V_EPI_RESIDUAL) v[j] *= gv[j];
         }
         if (EPI == LX2V_EPI_RESIDUAL) {
           float y[8];
-          const Frag8& rr = fw[2 + 2 * (mt & 1) + (it >> 1)];
+          const Frag8& rr = fw[2 + 2 * (mt % 3) + (it >> 1)];
           const i32x4 rh = (it & 1) ? rr.hi : rr.lo;
           unpack8(__builtin_bit_cast(u32x4, rh), y);
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = (float)(__bf16)v[j] + y[j];  // the product is rounded to bf16 before the add, as in the 8-wave kernels
         }
         const u32x4 out = pack8(v);
-        if (gm < p.M && col_ok) *reinterpret_cast<u32x4*>(p.C + (int64_t)gm * p.ldc + gn) = out;
+        __builtin_amdgcn_raw_buffer_store_b128(out, c_rs, col_ok ? (int)((int64_t)(gm - m0) * p.ldc * 2) + c_col : C_NOWHERE, 0, 0);
       }
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
@@ -445,7 +463,7 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_w8a8_w4_kernel(const GemmPara
 
   // ---- the stream ----
   int ord = 0, kt = 0;   // output tile ordinal and K-tile of stream position j
-  bool relaxed = false;  // the previous K-tile ended in the epilogue of an interior tile (32 stores per wave)
+  bool relaxed = false;  // the previous K-tile ended in an epilogue (32 stores per wave)
   int r5 = 0;            // (2 j) % 5: slot of A(j); W(j) r5 + 1, A(j+1) r5 + 2, W(j+1) r5 + 3, free r5 + 4 (all mod 5)
   auto slot = [&](int k) __attribute__((always_inline)) -> int {
     const int s5 = r5 + k;
@@ -459,7 +477,7 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_w8a8_w4_kernel(const GemmPara
     if (++kt == nk) {
       int m0, n0;
       tile_origin_w4(p, ord * grid + (int)blockIdx.x, m0, n0);
-      relaxed = m0 + BM <= p.M && n0 + BN <= p.N;
+      relaxed = !(W8_ABL & 8);
       if constexpr (!(W8_ABL & 8)) {
         epilogue(m0, n0, sw);  // W(j)'s slot is idle until A(j + 3) is staged into it, in the next first half ...
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
