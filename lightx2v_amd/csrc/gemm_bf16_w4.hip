@@ -365,25 +365,40 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_bf16_w4_kernel(const GemmPara
     load_resid(IntC<0>{});
     load_resid(IntC<1>{});
     load_resid(IntC<2>{});
+    // Software pipeline over the passes: the tuples of pass mt + 1 are written to the staging rows right behind the
+    // reads of pass mt and in front of its arithmetic (one wave's LDS instructions execute in order, so those
+    // writes cannot overtake the reads), i.e. the LDS round trip of a pass runs under the previous pass's
+    // conversions and stores.
+    auto write_pass = [&](auto mtc) __attribute__((always_inline)) {
+      constexpr int mt = decltype(mtc)::value;
+      if constexpr (mt < 8) {
+        static_for<0, 8>([&](auto ntc) __attribute__((always_inline)) {
+          constexpr int nt = decltype(ntc)::value;
+          acc_to_lds<acc_in_agpr(nt, mt)>(waddr[nt], acc[nt][mt]);
+        });
+      }
+    };
+    write_pass(IntC<0>{});
     static_for<0, 8>([&](auto mtc) __attribute__((always_inline)) {
       constexpr int mt = decltype(mtc)::value;
       load_resid(IntC<mt + 3>{});
-      static_for<0, 8>([&](auto ntc) __attribute__((always_inline)) {
-        constexpr int nt = decltype(ntc)::value;
-        acc_to_lds<acc_in_agpr(nt, mt)>(waddr[nt], acc[nt][mt]);
-      });
-      // (one wave's LDS instructions execute in order: the reads below see the writes above, and
-      // the next pass's writes come after these reads)
+      f32x4 lo[4], hi[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = it * 4 + fq;
+        const char* row = lds + epi_base + wid * 8192 + r * 512;
+        lo[it] = *reinterpret_cast<const f32x4*>(row + (((2 * fr) ^ r) << 4));
+        hi[it] = *reinterpret_cast<const f32x4*>(row + (((2 * fr + 1) ^ r) << 4));
+      }
+      asm volatile("" ::: "memory");
+      write_pass(IntC<mt + 1>{});
       static_for<0, 4>([&](auto itc) __attribute__((always_inline)) {
         constexpr int it = decltype(itc)::value;
         const int r = it * 4 + fq;
         const int gm = m0 + wm * 128 + mt * 16 + r;
-        const char* row = lds + epi_base + wid * 8192 + r * 512;
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(row + (((2 * fr) ^ r) << 4));
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(row + (((2 * fr + 1) ^ r) << 4));
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; }
+        for (int j = 0; j < 4; ++j) { v[j] = lo[it][j]; v[4 + j] = hi[it][j]; }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           v[j] += bv[j];
