@@ -72,7 +72,7 @@ def block_flops(S, D, H, F, T=TEXT_LEN):
     return self_attn, cross, gemm
 
 
-TRAFFIC_FILES = ("r02_attn_traffic.json", "r01_attn_traffic.json")  # newest first
+TRAFFIC_FILES = ("r03_attn_traffic.json", "r02_attn_traffic.json", "r01_attn_traffic.json")  # newest first
 
 
 def measured_traffic(S, heads_local):
