@@ -188,3 +188,51 @@ def test_key_split_of_the_last_round_of_a_launch_with_few_heads(case, options, h
         t[name] = (time.perf_counter() - t0) / 5 * 1e3
     fl = 4.0 * S * S * heads * D
     print(f"\n{heads} heads x {S} rows: rows split {t['plain']:.2f} ms ({fl / t['plain'] * 1e-9:.0f} TFLOP/s), with key split {t['split']:.2f} ms ({fl / t['split'] * 1e-9:.0f} TFLOP/s)")
+
+
+@pytest.mark.parametrize("side", ["few_cus", "all_cus"])
+def test_round_alignment_while_another_stream_takes_cus(case, options, side):
+    """Round alignment assumes one workgroup per CU and round; a collective's kernels (or any other stream's) take CUs
+    away while the attention runs, so rounds no longer line up and workgroups meet the wait's time limit instead of
+    their round-mates.  The result must not change and the launch must not take longer than the two workloads
+    back to back (plus slack): the wait is bounded, a missed alignment costs locality only."""
+    q, k, v, _, _ = case
+    options(attn_kernel=16, attn_qb=0, attn_tail=1, attn_round_sync=1)
+    base = hip.attn_fwd(q, k, v)
+    n = 256 if side == "few_cus" else 8192            # 256^2 outputs: a handful of workgroups per launch, like a collective's kernels
+    reps = 3000 if side == "few_cus" else 40
+    a = torch.randn(n, 8192, device=q.device, dtype=torch.bfloat16)
+    b = torch.randn(8192, n, device=q.device, dtype=torch.bfloat16)
+    other = torch.cuda.Stream()
+
+    def side_work():
+        with torch.cuda.stream(other):
+            for _ in range(reps):
+                torch.mm(a, b)
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return out, e0.elapsed_time(e1)
+
+    side_work()                                        # warm-up (rocBLAS picks and loads its kernel)
+    _, t_attn = timed(lambda: hip.attn_fwd(q, k, v))
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(other):
+        e0.record()
+    side_work()
+    with torch.cuda.stream(other):
+        e1.record()
+    torch.cuda.synchronize()
+    t_side = e0.elapsed_time(e1)
+    side_work()                                        # now both at once
+    got, t_both = timed(lambda: hip.attn_fwd(q, k, v))
+    torch.cuda.synchronize()
+    print(f"\nattention alone {t_attn:.1f} ms, side work ({side}) alone {t_side:.1f} ms, attention beside it {t_both:.1f} ms")
+    assert torch.equal(got, base)
+    assert t_both <= 1.25 * (t_attn + t_side) + 5.0
