@@ -27,6 +27,8 @@
 // four consecutive keys whose two blocks per 32-lane half lie 8 rows apart (conflict-free on the
 // 8-row x 32-column sub-tiled V image).  The K image is swizzled by the MFMA row index c instead
 // of the key index, which keeps its ds_read_b128 conflict-free under that row permutation.
+#include <algorithm>
+
 #include "attn_w4_common.h"
 
 using namespace lx2v_attn;
@@ -631,9 +633,18 @@ Plan make_plan(const lx2v_attn::AttnParams& p, int cus, int64_t max_split_bytes)
     Plan best{m, 0, p.sq, false, 1, rounds(wgs) * per_round(m)};
     if (!tail_on || wgs <= cus) return best;
     if (const int64_t rest = tail_of(m); rest > 0) {
-      const Plan c{m, 1, (nb - rest) * 64 * m, true, 1, (double)(wgs / cus) * per_round(m) + 1.3};
+      const int64_t row0 = (nb - rest) * 64 * m;
+      const Plan c{m, 1, row0, true, 1, (double)(wgs / cus) * per_round(m) + 1.3};
       if (c.cost < best.cost) best = c;
-      return best;  // (the measured case: kept as it is)
+      // ... or, given a workspace, the same rows as whole workgroups over 1 / sp of the keys each, as many ranges as
+      // fill one round (14B/720p: 8 workgroups x 32 ranges of 37 tiles instead of 37 workgroups of all 1182 tiles)
+      int sp = (int)std::min<int64_t>(std::min<int64_t>(32, cus / rest), ntiles / 8);
+      if (sp >= 2) sp = (int)((ntiles + (ntiles + sp - 1) / sp - 1) / ((ntiles + sp - 1) / sp));  // as many ranges as are not empty
+      if (sp >= 2 && split_bytes(p.sq - row0, 1, sp) <= max_split_bytes) {
+        const Plan k{m, m, row0, true, sp, (double)(wgs / cus) * per_round(m) + per_round(m) / sp + 0.08 + 0.1 + 0.15};
+        if (k.cost < best.cost) best = k;
+      }
+      return best;
     }
     // rows split: `full` full rounds of the main block count, the other rows of every head behind them
     const int64_t full = wgs / cus, nb_main = full * cus / p.heads;
@@ -674,8 +685,39 @@ int64_t lx2v_attn_x16_workspace_bytes(int64_t sq, int64_t skv, int heads) {
   lx2v_attn::AttnParams p{};
   p.sq = (int)sq; p.skv = (int)skv; p.heads = heads;
   const Plan plan = make_plan(p, device_cus(), INT64_MAX);
-  return plan.split > 1 ? (split_bytes(p.sq - plan.row0, heads, plan.split) + 255) / 256 * 256 : 0;
+  return plan.split > 1 ? (split_bytes(p.sq - plan.row0, plan.last_head_only ? 1 : heads, plan.split) + 255) / 256 * 256 : 0;
 }
+
+namespace {
+
+// Rows [row0, sq) of every head (or of the last head only), keys in `split` ranges of whole tiles: partial results
+// into the workspace, then the merge.
+int launch_key_split(const lx2v_attn::AttnParams& p, int64_t row0, int t, int split, bool last_head_only, hipStream_t st) {
+  lx2v_attn::AttnParams pp = p;
+  const int64_t h0 = last_head_only ? p.heads - 1 : 0;
+  const int64_t rest_rows = p.sq - row0;
+  const int64_t ntiles = (p.skv + KVB - 1) / KVB;
+  pp.q = p.q + row0 * p.ldq + h0 * HD;
+  pp.k = p.k + h0 * HD;
+  pp.v = p.v + h0 * HD;
+  pp.heads = last_head_only ? 1 : p.heads;
+  pp.sq = (int)rest_rows;
+  pp.nqb = (int)((rest_rows + 64 * t - 1) / (64 * t));
+  pp.nparts = split;
+  pp.part_keys = (int)((ntiles + split - 1) / split) * KVB;
+  pp.part_o = reinterpret_cast<float*>(p.workspace);
+  pp.part_ml = pp.part_o + rest_rows * pp.heads * split * HD;
+  const int64_t nwg = (int64_t)pp.nqb * pp.heads * split;
+  const int rc = t == 5 ? launch_with_rounds(attn_fwd_x16_kernel<true, 5>, attn_fwd_x16_kernel<false, 5>, X16_THREADS, pp, nwg, st, "attn_fwd(x16 key split)")
+                        : launch_with_rounds(attn_fwd_x16_kernel<true, 4>, attn_fwd_x16_kernel<false, 4>, X16_THREADS, pp, nwg, st, "attn_fwd(x16 key split)");
+  if (rc != LX2V_OK) return rc;
+  const int64_t threads = rest_rows * pp.heads * 32;
+  hipLaunchKernelGGL(attn_merge_parts_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, pp.part_o, pp.part_ml, p.out + row0 * p.ldo + h0 * HD, p.ldo,
+                     (int)rest_rows, pp.heads, split);
+  return LX2V_OK;
+}
+
+}  // namespace
 
 int lx2v_attn_launch_x16(const lx2v_attn::AttnParams& p, hipStream_t st) {
   const int cus = device_cus();
@@ -692,28 +734,11 @@ int lx2v_attn_launch_x16(const lx2v_attn::AttnParams& p, hipStream_t st) {
     const int rc = plan.m == 5 ? launch_with_rounds(attn_fwd_x16_kernel<true, 5>, attn_fwd_x16_kernel<false, 5>, X16_THREADS, pp, nwg, st, "attn_fwd(x16)")
                                : launch_with_rounds(attn_fwd_x16_kernel<true, 4>, attn_fwd_x16_kernel<false, 4>, X16_THREADS, pp, nwg, st, "attn_fwd(x16)");
     if (rc != LX2V_OK) return rc;
+    if (plan.split > 1) return launch_key_split(p, plan.row0, plan.t, plan.split, true, st);
     return launch_rows(p, plan.row0, p.sq, 1, true, st, "attn_fwd(x16 tail)");
   }
   const int rc = launch_rows(p, 0, plan.row0, plan.m, false, st, "attn_fwd(x16)");
   if (rc != LX2V_OK) return rc;
   if (plan.split == 1) return launch_rows(p, plan.row0, p.sq, plan.t, false, st, "attn_fwd(x16 rows tail)");
-  // rows [row0, sq) of every head, keys in `split` ranges of whole tiles -> partial results -> merge
-  lx2v_attn::AttnParams pp = p;
-  const int64_t rest_rows = p.sq - plan.row0;
-  const int64_t ntiles = (p.skv + KVB - 1) / KVB;
-  pp.q = p.q + plan.row0 * p.ldq;
-  pp.sq = (int)rest_rows;
-  pp.nqb = (int)((rest_rows + 64 * plan.t - 1) / (64 * plan.t));
-  pp.nparts = plan.split;
-  pp.part_keys = (int)((ntiles + plan.split - 1) / plan.split) * KVB;
-  pp.part_o = reinterpret_cast<float*>(p.workspace);
-  pp.part_ml = pp.part_o + rest_rows * p.heads * plan.split * HD;
-  const int64_t nwg = (int64_t)pp.nqb * p.heads * plan.split;
-  const int rc2 = plan.t == 5 ? launch_with_rounds(attn_fwd_x16_kernel<true, 5>, attn_fwd_x16_kernel<false, 5>, X16_THREADS, pp, nwg, st, "attn_fwd(x16 key split)")
-                              : launch_with_rounds(attn_fwd_x16_kernel<true, 4>, attn_fwd_x16_kernel<false, 4>, X16_THREADS, pp, nwg, st, "attn_fwd(x16 key split)");
-  if (rc2 != LX2V_OK) return rc2;
-  const int64_t threads = rest_rows * p.heads * 32;
-  hipLaunchKernelGGL(attn_merge_parts_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, pp.part_o, pp.part_ml, p.out + plan.row0 * p.ldo, p.ldo,
-                     (int)rest_rows, p.heads, plan.split);
-  return LX2V_OK;
+  return launch_key_split(p, plan.row0, plan.t, plan.split, false, st);
 }

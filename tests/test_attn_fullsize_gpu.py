@@ -236,3 +236,37 @@ def test_round_alignment_while_another_stream_takes_cus(case, options, side):
     print(f"\nattention alone {t_attn:.1f} ms, side work ({side}) alone {t_side:.1f} ms, attention beside it {t_both:.1f} ms")
     assert torch.equal(got, base)
     assert t_both <= 1.25 * (t_attn + t_side) + 5.0
+
+
+def test_key_split_of_the_last_heads_tail(case, options):
+    """Many heads: the last, sparse round is a few workgroups of the last head (here 13 x 237 = 12 rounds of 256 + 9).
+    Without a workspace those rows go to 64-row workgroups over all keys; with one, to 320-row workgroups over 1 / 28
+    of the keys each (9 x 28 = 252 workgroups: one short round) and a merge.  Everything else is the same arithmetic."""
+    import time
+
+    q, k, v, rows, ref = case
+    options(attn_kernel=16, attn_qb=5, attn_tail=1)
+    need = hip.attn_workspace_bytes(S, S, H)
+    first_tail_row = (237 - 9) * 320
+    assert need >= (S - first_tail_row) * 28 * (D + 2) * 4
+    ws = torch.empty(need, dtype=torch.uint8, device=q.device)
+    plain = hip.attn_fwd(q, k, v)
+    split = hip.attn_fwd(q, k, v, workspace=ws)
+    assert torch.equal(hip.attn_fwd(q, k, v, workspace=ws), split)         # deterministic
+    assert torch.equal(split[:first_tail_row], plain[:first_tail_row])
+    assert torch.equal(split[:, :(H - 1) * D], plain[:, :(H - 1) * D])
+    assert not torch.equal(split[first_tail_row:, (H - 1) * D:], plain[first_tail_row:, (H - 1) * D:])   # the split is live
+    assert (split.float() - plain.float()).abs().max().item() <= 2e-3
+    got = split[rows.to(split.device)].float().cpu()
+    assert cos(got, ref) >= 0.9999
+    assert torch.nn.functional.cosine_similarity(got, ref, dim=1).min().item() >= 0.999
+    assert torch.equal(hip.attn_fwd(q, k, v, workspace=ws[:4096]), plain)   # a workspace that is too small only limits the plan
+    t = {}
+    for name, w in (("plain", None), ("split", ws)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            hip.attn_fwd(q, k, v, workspace=w)
+        torch.cuda.synchronize()
+        t[name] = (time.perf_counter() - t0) / 5 * 1e3
+    print(f"\n13 heads x {S}: 64-row tail {t['plain']:.2f} ms, key-split tail {t['split']:.2f} ms")
