@@ -166,6 +166,21 @@ int lx2v_gemm_bf16(const uint16_t* A, int64_t lda, const lx2v_kseg* kseg,
                    uint16_t* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
                    const uint16_t* resid, int64_t ldr, const float* gate, void* stream);
 
+/* The same with a caller-owned workspace (no counterpart in the reference).  Output tiles are computed in rounds of
+ * one 256x256 tile per CU; when the last round would fill at most a quarter of the CUs (5920 tiles on 256 CUs:
+ * 23 rounds + 32 tiles) and K >= 4096, those tiles are split along K over all CUs instead: raw fp32 partial sums go
+ * to the workspace, a last small launch adds them in a fixed order and applies the epilogue.  The tail tiles'
+ * outputs then differ from lx2v_gemm_bf16's by fp32 summation order (deterministic from call to call); every other
+ * output is bit-identical.  lx2v_gemm_bf16_workspace_bytes: what a call of that shape can use (0: it would not
+ * split); a NULL, misaligned (16 bytes) or smaller workspace only switches the split off.  Calls that share a
+ * workspace must be ordered (one stream).  Not used with a segmented A. */
+int64_t lx2v_gemm_bf16_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int lx2v_gemm_bf16_ws(const uint16_t* A, int64_t lda, const lx2v_kseg* kseg,
+                      const uint16_t* W, int64_t ldw, const float* bias,
+                      uint16_t* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
+                      const uint16_t* resid, int64_t ldr, const float* gate,
+                      void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- Attention forward: out = softmax(q k^T * scale) v, non-causal, no mask, batch 1 --------
  * q [sq, heads, head_dim], k/v [skv, heads, head_dim], out [sq, heads*head_dim]; token strides
  * ld* in elements, heads are contiguous blocks of head_dim inside a token row.  head_dim must

@@ -411,12 +411,31 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_pp_kernel(const GemmParams
 
 }  // namespace
 
-int lx2v_gemm_launch_w4(lx2v_gemm::GemmParams& p, int epilogue, hipStream_t st);  // gemm_bf16_w4.hip
+int lx2v_gemm_launch_w4(lx2v_gemm::GemmParams& p, int epilogue, void* workspace, int64_t workspace_bytes, hipStream_t st);  // gemm_bf16_w4.hip
+int64_t lx2v_gemm_w4_workspace_bytes(const lx2v_gemm::GemmParams& p);
 
 extern "C" int lx2v_gemm_bf16(const uint16_t* A, int64_t lda, const lx2v_kseg* kseg,
                               const uint16_t* W, int64_t ldw, const float* bias,
                               uint16_t* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
                               const uint16_t* resid, int64_t ldr, const float* gate, void* stream) {
+  return lx2v_gemm_bf16_ws(A, lda, kseg, W, ldw, bias, C, ldc, M, N, K, epilogue, resid, ldr, gate, nullptr, 0, stream);
+}
+
+extern "C" int64_t lx2v_gemm_bf16_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0 || M >= (1LL << 31) || N >= (1LL << 31) || K >= (1LL << 31) || K % BK != 0) return 0;
+  GemmParams p{};
+  p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  p.tiles_m = (int)((M + BM - 1) / BM);
+  p.tiles_n = (int)((N + BN - 1) / BN);
+  if ((int64_t)p.tiles_m * p.tiles_n >= (1LL << 31) || lx2v_options().gemm_kernel != 0) return 0;
+  return lx2v_gemm_w4_workspace_bytes(p);
+}
+
+extern "C" int lx2v_gemm_bf16_ws(const uint16_t* A, int64_t lda, const lx2v_kseg* kseg,
+                                 const uint16_t* W, int64_t ldw, const float* bias,
+                                 uint16_t* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
+                                 const uint16_t* resid, int64_t ldr, const float* gate,
+                                 void* workspace, int64_t workspace_bytes, void* stream) {
   LX2V_REQUIRE(M == 0 || (A && W && C), LX2V_EINVAL, "gemm: null tensor");
   LX2V_REQUIRE(M >= 0 && N > 0 && K > 0, LX2V_EINVAL, "gemm: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
   LX2V_REQUIRE(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), LX2V_EUNSUP, "gemm: dimensions must fit in 31 bits");
@@ -475,7 +494,7 @@ extern "C" int lx2v_gemm_bf16(const uint16_t* A, int64_t lda, const lx2v_kseg* k
   // one barrier per K-tile, 2 = 8 waves in the ping-pong schedule.  All three give identical results.
   const int which = lx2v_options().gemm_kernel;
   if (which == 0 && p.a_bytes < (1LL << 32) && p.w_bytes < (1LL << 32) && ldc < (1LL << 22)) {  // (its stores address one 256-row panel of C with 31 bits)
-    const int rc = lx2v_gemm_launch_w4(p, epilogue, st);
+    const int rc = lx2v_gemm_launch_w4(p, epilogue, workspace, workspace_bytes, st);
     if (rc != LX2V_OK) return rc;
     LX2V_CHECK_LAUNCH("gemm(persistent)");
     return LX2V_OK;

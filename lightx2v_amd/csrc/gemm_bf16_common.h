@@ -20,6 +20,13 @@ struct GemmParams {
   int64_t a_bytes, w_bytes;  // extent of A / W from their first element to the end of the last row read
   int M, N, K;
   int tiles_m, tiles_n;
+  // Persistent kernel: the tiles it runs (virtual block ids below ntiles_run).  When the last round of one tile per
+  // CU would be sparsely filled, its tiles [tail_first, tiles_m * tiles_n) are left to a second launch that splits
+  // their K range into tail_split parts of tail_nk K-tiles (one workgroup per part, raw fp32 accumulators into
+  // `partials` in fragment order) and a third that sums the parts in a fixed order and applies the epilogue.
+  int ntiles_run;
+  int tail_first, tail_split, tail_nk;
+  float* partials;
 };
 
 }  // namespace lx2v_gemm

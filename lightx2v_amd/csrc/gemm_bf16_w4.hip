@@ -39,6 +39,8 @@
 #ifndef LX2V_GROUP_M
 #define LX2V_GROUP_M 4  // measured: 4 row panels per column sweep beat 8 and 16 for this kernel (3.15 vs 3.30 vs 3.66 ms at [75600, 5120] x [5120, 5120])
 #endif
+#include <algorithm>
+
 #include "gemm_bf16_common.h"
 
 namespace {
@@ -53,6 +55,7 @@ namespace {
 #define W4_ABL 0  // timing ablations (wrong results): 1 no LDS-DMA in the loop, 2 no fragment reads, 4 no wait + barrier per K-tile, 8 no epilogue, 16 no MFMAs, 32 wait for the DMA only (no barrier), 64 barrier only (no waits), 128 no relaxed wait behind an epilogue, 256 every workgroup stages tile (0, 0) (all L2 hits), 512 the epilogue computes but does not store
 #endif
 constexpr int W4_THREADS = 256;
+constexpr int EPI_PARTIAL = 3;                // kernel instance that leaves raw fp32 accumulators of a K range (internal)
 constexpr int NSLOT = 5;                      // ring of operand K-tiles
 constexpr int W4_LDS = NSLOT * TILE_BYTES;    // all 160 KiB of the CU
 
@@ -89,6 +92,12 @@ LX2V_DEVICE void acc_to_lds(int lds_addr, const f32x4& acc) {
   if constexpr (IN_AGPR) asm volatile("ds_write_b128 %0, %1" ::"v"(lds_addr), "a"(acc) : "memory");
   else asm volatile("ds_write_b128 %0, %1" ::"v"(lds_addr), "v"(acc) : "memory");
 }
+// ... or of a global store at `sbase` (wave-uniform) + `voff` bytes.
+template <bool IN_AGPR>
+LX2V_DEVICE void acc_to_global(int voff, const f32x4& acc, uint64_t sbase) {
+  if constexpr (IN_AGPR) asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(voff), "a"(acc), "s"(sbase) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(voff), "v"(acc), "s"(sbase) : "memory");
+}
 template <int NT, int MT>
 LX2V_DEVICE void pin_acc(f32x4& acc) {
   if constexpr (acc_in_agpr(NT, MT)) asm volatile("" : "+a"(acc));
@@ -115,9 +124,19 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_bf16_w4_kernel(const GemmPara
   const int wm = wid >> 1, wn = wid & 1;
   const int fr = lane & 15, fq = lane >> 4;
 
-  const int ntiles = p.tiles_m * p.tiles_n;
+  // EPI == EPI_PARTIAL: one workgroup per (tail tile, K range); everything else is the same stream of one item.
+  constexpr bool PARTIAL = EPI == EPI_PARTIAL;
+  const int ntiles = p.ntiles_run;
   const int grid = gridDim.x;
-  const int nk = p.K / BK;
+  int nk = p.K / BK;
+  int part_vbid = 0;      // virtual block id of the partial item's tile
+  int64_t k_first = 0;    // first K column of the item
+  if constexpr (PARTIAL) {
+    const int item = blockIdx.x, part = item % p.tail_split;
+    part_vbid = p.tail_first + item / p.tail_split;
+    k_first = (int64_t)part * p.tail_nk * BK;
+    nk = min(p.tail_nk, nk - part * p.tail_nk);
+  }
 
   // ---- staging: DMA instruction q (0..7) of wave w fills rows 64 w + 8 q .. + 7 of the tile image
   // (1 KiB of LDS, lane L the 16 bytes at 16 L: row 64 w + 8 q + (L >> 3), position L & 7 holding
@@ -150,18 +169,18 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_bf16_w4_kernel(const GemmPara
   // empty (0 bytes): the DMA instructions of the stream's last two K-tiles then fetch nothing and
   // write zeros into a stage nobody reads, so the loop body needs no "last tiles" variants.
   auto d_panel = [&]() __attribute__((always_inline)) {
-    const int vbid = d_ord * grid + (int)blockIdx.x;
-    const bool live = vbid < ntiles;
+    const int vbid = PARTIAL ? part_vbid : d_ord * grid + (int)blockIdx.x;
+    const bool live = PARTIAL ? d_ord == 0 : vbid < ntiles;
     int m0 = 0, n0 = 0;
     if (live && !(W4_ABL & 256)) tile_origin(p, vbid, m0, n0);
     const int64_t ld = d_region ? p.lda2 : p.lda;
-    a_rs = raw_descriptor(p.A + (int64_t)m0 * ld, live ? p.a_bytes - (int64_t)m0 * ld * 2 : 0);
+    a_rs = raw_descriptor(p.A + k_first + (int64_t)m0 * ld, live ? p.a_bytes - ((int64_t)m0 * ld + k_first) * 2 : 0);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       a_pv[q] = piece_voff(q, ld);
       asm volatile("" : "+v"(a_pv[q]));
     }
-    w_rs = raw_descriptor(p.W + (int64_t)n0 * p.ldw, live ? p.w_bytes - (int64_t)n0 * p.ldw * 2 : 0);
+    w_rs = raw_descriptor(p.W + k_first + (int64_t)n0 * p.ldw, live ? p.w_bytes - ((int64_t)n0 * p.ldw + k_first) * 2 : 0);
   };
   d_panel();
 
@@ -420,8 +439,24 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_bf16_w4_kernel(const GemmPara
     });
   };
 
+  // ---- a partial item's result: the raw accumulators, tuple by tuple in fragment order (1 KiB per wave and tuple) ----
+  auto store_partial = [&]() __attribute__((always_inline)) {
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");  // the last MFMAs were issued a few cycles ago
+    const float* base = p.partials + ((int64_t)blockIdx.x * 4 + wid) * (64 * 64 * 4);
+    const uint64_t bu = reinterpret_cast<uint64_t>(base);
+    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)bu), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(bu >> 32));
+    const uint64_t sbase = ((uint64_t)bhi << 32) | blo;
+    static_for<0, 8>([&](auto ntc) __attribute__((always_inline)) {
+      static_for<0, 8>([&](auto mtc) __attribute__((always_inline)) {
+        constexpr int nt = decltype(ntc)::value, mt = decltype(mtc)::value;
+        const int voff = lane * 16 + (nt * 8 + mt) * 1024;
+        acc_to_global<acc_in_agpr(nt, mt)>(voff, acc[nt][mt], sbase);
+      });
+    });
+  };
+
   // ---- prologue: half-tiles 0..3 (K-tiles 0 and 1 of the stream), then the fragments of (0, 0) ----
-  const int my_tiles = (int)blockIdx.x < ntiles ? (ntiles - 1 - (int)blockIdx.x) / grid + 1 : 0;
+  const int my_tiles = PARTIAL ? 1 : (int)blockIdx.x < ntiles ? (ntiles - 1 - (int)blockIdx.x) / grid + 1 : 0;
   const int64_t total = (int64_t)my_tiles * nk;  // K-tiles in this workgroup's stream
   if (total == 0) return;
   static_for<0, 2>([&](auto tc) __attribute__((always_inline)) {
@@ -465,6 +500,10 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_bf16_w4_kernel(const GemmPara
     d_advance();
     relaxed = false;
     if (++kt == nk) {
+      if constexpr (PARTIAL) {
+        store_partial();
+        break;
+      }
       int m0, n0;
       tile_origin(p, ord * grid + (int)blockIdx.x, m0, n0);
       relaxed = !(W4_ABL & (8 | 512));
@@ -488,11 +527,70 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_bf16_w4_kernel(const GemmPara
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may still be writing this workgroup's LDS when it ends
 }
 
-}  // namespace
+// Tail tiles of a launch whose last round was split along K: one thread sums the parts of 8 consecutive outputs
+// of a row in a fixed order (part 0 first) and applies the epilogue of the persistent kernel, same arithmetic.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_tail_fixup_kernel(const GemmParams p) {
+  const int t = blockIdx.x >> 5;  // tail tile
+  const int e = ((blockIdx.x & 31) << 8) + threadIdx.x;
+  const int r = e & 255, c = (e >> 8) * 8;  // consecutive threads: consecutive rows (consecutive lanes of a fragment)
+  int m0, n0;
+  tile_origin(p, p.tail_first + t, m0, n0);
+  const int gm = m0 + r, gn = n0 + c;
+  if (gm >= p.M || gn >= p.N) return;
+  const int wave = (r >> 7) * 2 + (c >> 7), mt = (r & 127) >> 4, fr = r & 15, nt = (c & 127) >> 4, fq0 = (c & 15) >> 2;
+  const float* src = p.partials + ((((int64_t)t * p.tail_split * 4 + wave) * 64 + nt * 8 + mt) * 64 + fq0 * 16 + fr) * 4;
+  const int64_t part_stride = (int64_t)4 * 64 * 64 * 4;  // floats per item
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int part = 0; part < p.tail_split; ++part) {
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(src + part * part_stride);
+    const f32x4 hi = *reinterpret_cast<const f32x4*>(src + part * part_stride + 64);  // the next column group: 16 lanes on
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] += lo[j]; v[4 + j] += hi[j]; }
+  }
+  float bv[8], gv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    bv[j] = p.bias != nullptr ? p.bias[gn + j] : 0.f;
+    gv[j] = (EPI == LX2V_EPI_RESIDUAL && p.gate != nullptr) ? p.gate[gn + j] : 1.f;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    v[j] += bv[j];
+    if (EPI == LX2V_EPI_GELU_TANH) v[j] = gelu_tanh(v[j]);
+    if (EPI == LX2V_EPI_RESIDUAL) v[j] *= gv[j];
+  }
+  if (EPI == LX2V_EPI_RESIDUAL) {
+    float y[8];
+    unpack8(*reinterpret_cast<const u32x4*>(p.resid + (int64_t)gm * p.ldr + gn), y);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)(__bf16)v[j] + y[j];
+  }
+  *reinterpret_cast<u32x4*>(p.C + (int64_t)gm * p.ldc + gn) = pack8(v);
+}
 
-// Launch for p already validated by lx2v_gemm_bf16.  One workgroup per CU (the 160 KiB of LDS allow
-// no second one), never more than there are tiles.
-int lx2v_gemm_launch_w4(lx2v_gemm::GemmParams& p, int epilogue, hipStream_t st) {
+struct TailPlan {
+  int rem, split, nk_part;
+  int64_t bytes;
+};
+
+// Is the last round of one tile per CU worth splitting along K?  Only when at most a quarter of the CUs would
+// have a tile in it, K is long enough for two more launches to pay, and A is a plain matrix.
+TailPlan tail_plan(const GemmParams& p, int cus) {
+  TailPlan t{0, 1, 0, 0};
+  const int64_t ntiles = (int64_t)p.tiles_m * p.tiles_n;
+  const int nk = p.K / BK;
+  if (ntiles <= cus || p.a_kseg != 0 || nk < 64) return t;
+  const int rem = (int)(ntiles % cus);
+  if (rem == 0 || rem * 4 > cus) return t;
+  int split = std::min(cus / rem, 16);
+  const int per = (nk + split - 1) / split;
+  split = (nk + per - 1) / per;  // as many parts as are not empty
+  t = TailPlan{rem, split, per, (int64_t)rem * split * 4 * 64 * 64 * 4 * (int64_t)sizeof(float)};
+  return t;
+}
+
+int device_cus() {
   static int cus_cached[64];
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
@@ -502,12 +600,41 @@ int lx2v_gemm_launch_w4(lx2v_gemm::GemmParams& p, int epilogue, hipStream_t st) 
     }
     cus = cus_cached[dev];
   }
+  return cus;
+}
+
+}  // namespace
+
+// Workspace a call of this shape can use (0: its last round is not split).
+int64_t lx2v_gemm_w4_workspace_bytes(const lx2v_gemm::GemmParams& p) { return tail_plan(p, device_cus()).bytes; }
+
+// Launch for p already validated by lx2v_gemm_bf16.  One workgroup per CU (the 160 KiB of LDS allow
+// no second one), never more than there are tiles.  With a workspace, a sparsely filled last round
+// becomes a K split of its tiles (see GemmParams).
+int lx2v_gemm_launch_w4(lx2v_gemm::GemmParams& p, int epilogue, void* workspace, int64_t workspace_bytes, hipStream_t st) {
+  const int cus = device_cus();
   const int64_t ntiles = (int64_t)p.tiles_m * p.tiles_n;
-  const dim3 grid((unsigned)(ntiles < cus ? ntiles : cus)), block(W4_THREADS);
+  TailPlan tp = tail_plan(p, cus);
+  if (tp.bytes == 0 || workspace == nullptr || (reinterpret_cast<uintptr_t>(workspace) & 15u) != 0 || workspace_bytes < tp.bytes) tp = TailPlan{0, 1, 0, 0};
+  p.ntiles_run = (int)(ntiles - tp.rem);
+  p.tail_first = p.ntiles_run;
+  p.tail_split = tp.split;
+  p.tail_nk = tp.nk_part;
+  p.partials = reinterpret_cast<float*>(workspace);
+  const dim3 grid((unsigned)(p.ntiles_run < cus ? p.ntiles_run : cus)), block(W4_THREADS);
   switch (epilogue) {
     case LX2V_EPI_NONE: hipLaunchKernelGGL(gemm_bf16_w4_kernel<LX2V_EPI_NONE>, grid, block, 0, st, p); break;
     case LX2V_EPI_GELU_TANH: hipLaunchKernelGGL(gemm_bf16_w4_kernel<LX2V_EPI_GELU_TANH>, grid, block, 0, st, p); break;
     default: hipLaunchKernelGGL(gemm_bf16_w4_kernel<LX2V_EPI_RESIDUAL>, grid, block, 0, st, p); break;
+  }
+  if (tp.rem > 0) {
+    hipLaunchKernelGGL(gemm_bf16_w4_kernel<EPI_PARTIAL>, dim3((unsigned)(tp.rem * tp.split)), block, 0, st, p);
+    const dim3 fgrid((unsigned)(tp.rem * 32));
+    switch (epilogue) {
+      case LX2V_EPI_NONE: hipLaunchKernelGGL(gemm_tail_fixup_kernel<LX2V_EPI_NONE>, fgrid, dim3(256), 0, st, p); break;
+      case LX2V_EPI_GELU_TANH: hipLaunchKernelGGL(gemm_tail_fixup_kernel<LX2V_EPI_GELU_TANH>, fgrid, dim3(256), 0, st, p); break;
+      default: hipLaunchKernelGGL(gemm_tail_fixup_kernel<LX2V_EPI_RESIDUAL>, fgrid, dim3(256), 0, st, p); break;
+    }
   }
   return LX2V_OK;
 }

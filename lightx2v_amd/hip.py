@@ -34,6 +34,8 @@ _SIGNATURES = {
     "lx2v_gelu_tanh_bf16": [_P, _P, _I64, _P],
     "lx2v_gelu_erf_bf16": [_P, _P, _I64, _P],
     "lx2v_gemm_bf16": [_P, _I64, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _I64, _I, _P, _I64, _P, _P],
+    "lx2v_gemm_bf16_ws": [_P, _I64, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _I64, _I, _P, _I64, _P, _P, _I64, _P],
+    "lx2v_gemm_bf16_workspace_bytes": [_I64, _I64, _I64],
     "lx2v_attn_fwd_bf16": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I, _I, _F, _P, _P],
     "lx2v_attn_fwd_bf16_ws": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I, _I, _F, _P, _P, _I64, _P],
     "lx2v_attn_bf16_workspace_bytes": [_I64, _I64, _I],
@@ -86,7 +88,7 @@ def load() -> ctypes.CDLL:
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_int64 if name in ("lx2v_attn_fp8_workspace_bytes", "lx2v_attn_fp8_static_bytes", "lx2v_attn_bf16_workspace_bytes") else ctypes.c_int
+        fn.restype = ctypes.c_int64 if name in ("lx2v_attn_fp8_workspace_bytes", "lx2v_attn_fp8_static_bytes", "lx2v_attn_bf16_workspace_bytes", "lx2v_gemm_bf16_workspace_bytes") else ctypes.c_int
     lib.lx2v_abi_version.restype = ctypes.c_int
     lib.lx2v_last_error.restype = ctypes.c_char_p
     _lib = lib
@@ -332,11 +334,34 @@ def gelu_tanh(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tens
     return out
 
 
+def gemm_workspace_bytes(M: int, N: int, K: int) -> int:
+    """Bytes of partial sums `gemm` can use for a call of this shape (0: its last round of tiles is not split along K)."""
+    return int(load().lx2v_gemm_bf16_workspace_bytes(int(M), int(N), int(K)))
+
+
+_GEMM_WORKSPACES = {}
+
+
+def gemm_workspace_for(a: torch.Tensor, N: int, K: int) -> Optional[torch.Tensor]:
+    """One workspace per device, grown to the largest request, for callers that issue their GEMMs on one stream
+    (calls that share a workspace must be ordered); None when the shape would not use one."""
+    need = gemm_workspace_bytes(a.shape[0], N, K)
+    if need == 0:
+        return None
+    ws = _GEMM_WORKSPACES.get(a.device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=a.device)
+        _GEMM_WORKSPACES[a.device] = ws
+    return ws
+
+
 def gemm(a: torch.Tensor, w_out_in: torch.Tensor, bias=None, epilogue: int = EPI_NONE, resid: Optional[torch.Tensor] = None,
-         gate=None, out: Optional[torch.Tensor] = None, kseg: Optional[KSeg] = None) -> torch.Tensor:
+         gate=None, out: Optional[torch.Tensor] = None, kseg: Optional[KSeg] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
     """C = epilogue(a @ w_out_in.T + bias).  a [M,K] bf16, w_out_in [N,K] bf16 (checkpoint layout).
     With `kseg`, `a` is [M, seg] rows of the FIRST segment and the other segments are found through
-    the strides in `kseg` (the caller guarantees they lie inside one allocation)."""
+    the strides in `kseg` (the caller guarantees they lie inside one allocation).
+    `workspace`: an optional uint8 GPU tensor (`gemm_workspace_bytes`) that lets a sparsely filled last round of
+    output tiles be split along K; those tiles' outputs then differ from the plain call's by fp32 summation order."""
     _need_bf16_cuda("gemm.a", a)
     _need_bf16_cuda("gemm.w", w_out_in)
     assert a.dim() == 2 and w_out_in.dim() == 2
@@ -354,9 +379,11 @@ def gemm(a: torch.Tensor, w_out_in: torch.Tensor, bias=None, epilogue: int = EPI
         _need_out("gemm.resid", resid, (M, N), a)
     elif epilogue == EPI_RESIDUAL:
         raise Lx2vError("gemm: the residual epilogue needs `resid`")
-    st = load().lx2v_gemm_bf16(a.data_ptr(), a.stride(0), None if kseg is None else ctypes.byref(kseg), w_out_in.data_ptr(), w_out_in.stride(0), _ptr(b),
-                               out.data_ptr(), out.stride(0), M, N, K, epilogue, _ptr(resid), 0 if resid is None else resid.stride(0),
-                               _ptr(g), _stream())
+    if workspace is not None and (workspace.dtype != torch.uint8 or workspace.device != a.device or not workspace.is_contiguous()):
+        raise Lx2vError("gemm: workspace must be a contiguous uint8 tensor on the operands' device")
+    st = load().lx2v_gemm_bf16_ws(a.data_ptr(), a.stride(0), None if kseg is None else ctypes.byref(kseg), w_out_in.data_ptr(), w_out_in.stride(0), _ptr(b),
+                                  out.data_ptr(), out.stride(0), M, N, K, epilogue, _ptr(resid), 0 if resid is None else resid.stride(0),
+                                  _ptr(g), _ptr(workspace), 0 if workspace is None else workspace.numel(), _stream())
     _check(st, "lx2v_gemm_bf16")
     return out
 

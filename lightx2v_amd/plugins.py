@@ -278,10 +278,15 @@ class HipMMWeight:
     def apply(self, input_tensor, out=None):
         """`out`: optional preallocated [M, N] destination (row stride free), e.g. a row range of a
         larger buffer; the reference signature has no such slot and allocates."""
-        return hip.gemm(input_tensor, self.weight_nk, self.bias, out=out)
+        return hip.gemm(input_tensor, self.weight_nk, self.bias, out=out, workspace=self._workspace(input_tensor))
+
+    def _workspace(self, input_tensor, kseg=None):
+        """The device's shared GEMM workspace when this product's last round of tiles is worth a K split
+        (every Linear of a forward runs on one stream, so one workspace per device serves them all)."""
+        return None if kseg is not None else hip.gemm_workspace_for(input_tensor, *self.weight_nk.shape)
 
     def apply_gelu(self, input_tensor):
-        return hip.gemm(input_tensor, self.weight_nk, self.bias, epilogue=hip.EPI_GELU_TANH)
+        return hip.gemm(input_tensor, self.weight_nk, self.bias, epilogue=hip.EPI_GELU_TANH, workspace=self._workspace(input_tensor))
 
     def apply_residual_(self, input_tensor, resid, gate=None, kseg=None):
         """resid <- resid + (x W^T + b) * gate, in place; returns resid.  `kseg` (hip.KSeg): the
@@ -289,8 +294,9 @@ class HipMMWeight:
         A per-token gate (hip.RowMod) does not fit the GEMM epilogue's [N] gate vector: the product is
         formed first and the gated add is its own pass."""
         if isinstance(gate, hip.RowMod) or resid.dtype == torch.float32:   # (an fp32 residual stream is not the epilogue's bf16 slot either)
-            return hip.gate_residual_(resid, hip.gemm(input_tensor, self.weight_nk, self.bias, kseg=kseg), gate)
-        return hip.gemm(input_tensor, self.weight_nk, self.bias, epilogue=hip.EPI_RESIDUAL, resid=resid, gate=gate, out=resid, kseg=kseg)
+            return hip.gate_residual_(resid, hip.gemm(input_tensor, self.weight_nk, self.bias, kseg=kseg, workspace=self._workspace(input_tensor, kseg)), gate)
+        return hip.gemm(input_tensor, self.weight_nk, self.bias, epilogue=hip.EPI_RESIDUAL, resid=resid, gate=gate, out=resid, kseg=kseg,
+                        workspace=self._workspace(input_tensor, kseg))
 
 
 @MM_WEIGHT_REGISTER("hip-fp8")

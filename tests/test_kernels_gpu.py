@@ -217,6 +217,71 @@ def test_gemm_many_tiles_per_workgroup(cuda, M, N, K, epi, options):
     assert (got - want).abs().max().item() <= 2 * BF16_EPS * want.abs().max().item()
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(4352, 4096, 4096, "none"),      # 17 x 16 = 272 tiles: one round + 16, split 16 ways (4 K-tiles each)
+                                       (4300, 4104, 4160, "resid"),     # the same grid with a ragged last row panel / column, 65 K-tiles -> 13 parts of 5
+                                       (75600, 5120, 5120, "gelu"),     # 14B output projection shape: 23 rounds + 32 tiles, 8 parts of 10 K-tiles
+                                       (75600, 5120, 13824, "resid")])  # 14B FFN-2: 8 parts of 27 K-tiles
+def test_gemm_k_split_of_a_sparse_last_round(cuda, M, N, K, epi, options):
+    """With a workspace the tiles of a sparsely filled last round are split along K over all CUs (raw fp32 partial
+    sums, summed in a fixed order by a fix-up launch that applies the epilogue).  Everything outside those tiles is
+    bit-identical to the plain call; inside, the outputs differ by fp32 summation order only; both match the
+    fp32 product on the CPU on sampled rows."""
+    g = torch.Generator(device=cuda).manual_seed(70)
+    a = torch.randn(M, K, generator=g, device=cuda, dtype=torch.float32).to(torch.bfloat16)
+    w = (0.05 * torch.randn(N, K, generator=g, device=cuda, dtype=torch.float32)).to(torch.bfloat16)
+    b = 0.1 * torch.randn(N, generator=g, device=cuda, dtype=torch.float32)
+    gate = torch.randn(N, generator=g, device=cuda, dtype=torch.float32)
+    resid = torch.randn(M, N, generator=g, device=cuda, dtype=torch.float32).to(torch.bfloat16) if epi == "resid" else None
+    options(gemm_kernel=0)
+    need = hip.gemm_workspace_bytes(M, N, K)
+    tiles = -(-M // 256) * -(-N // 256)
+    rem = tiles % 256
+    assert need > 0 and need % (rem * 256 * 256 * 4) == 0
+    ws = torch.empty(need, dtype=torch.uint8, device=cuda)
+
+    def run(workspace):
+        if epi == "gelu":
+            return hip.gemm(a, w, b, epilogue=hip.EPI_GELU_TANH, workspace=workspace)
+        if epi == "resid":
+            return hip.gemm(a, w, b, epilogue=hip.EPI_RESIDUAL, resid=resid, gate=gate, workspace=workspace)
+        return hip.gemm(a, w, b, workspace=workspace)
+
+    plain = run(None)
+    split = run(ws)
+    assert torch.equal(run(ws), split)                       # deterministic
+    assert torch.equal(run(ws[:need - 16]), plain)           # too small a workspace only switches the split off
+    diff = plain != split
+    assert bool(diff.any())                                  # the split is live
+    # the differing outputs lie in at most `rem` tiles ...
+    pad = torch.zeros(-(-M // 256) * 256, -(-N // 256) * 256, dtype=torch.bool, device=cuda)
+    pad[:M, :N] = diff
+    touched = pad.view(-(-M // 256), 256, -(-N // 256), 256).any(dim=3).any(dim=1)
+    assert int(touched.sum()) <= rem, (int(touched.sum()), rem)
+    # ... and are roundings of nearly equal fp32 values: one bf16 step at most
+    scale = plain.float().abs().max().item()
+    assert (plain.float() - split.float()).abs().max().item() <= 2 * BF16_EPS * scale
+    assert int(diff.sum()) <= 0.02 * rem * 65536
+    tm, tn = (int(v) for v in touched.nonzero()[0])
+    rows = torch.tensor(sorted({0, M - 1, tm * 256, min(tm * 256 + 255, M - 1)} | set(torch.randint(0, M, (24,), generator=torch.Generator().manual_seed(71)).tolist())))
+    want = a[rows.to(cuda)].float().cpu() @ w.float().cpu().t() + b.cpu()
+    if epi == "gelu":
+        want = torch.nn.functional.gelu(want, approximate="tanh")
+    if epi == "resid":
+        want = resid[rows.to(cuda)].float().cpu() + want.to(torch.bfloat16).float() * gate.cpu()
+    got = split[rows.to(cuda)].float().cpu()
+    assert (got - want).abs().max().item() <= 2 * BF16_EPS * want.abs().max().item() + 1e-3
+
+
+def test_gemm_workspace_query_says_when_a_split_pays(cuda, options):
+    options(gemm_kernel=0)
+    assert hip.gemm_workspace_bytes(75600, 5120, 5120) == 32 * 8 * 256 * 256 * 4      # 5920 tiles on 256 CUs
+    assert hip.gemm_workspace_bytes(75600, 15360, 5120) == 0                          # last round 96 tiles: more than a quarter of the CUs
+    assert hip.gemm_workspace_bytes(4352, 4096, 2048) == 0                            # K too short for two more launches to pay
+    assert hip.gemm_workspace_bytes(2048, 2048, 8192) == 0                            # a single round
+    options(gemm_kernel=1)
+    assert hip.gemm_workspace_bytes(75600, 5120, 5120) == 0                           # only the persistent kernel splits
+
+
 def test_gemm_mfma_operand_orientation_identity(cuda):
     """A = I against an ASYMMETRIC W catches a transposed accumulator write-back."""
     n = 256

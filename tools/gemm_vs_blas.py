@@ -39,6 +39,9 @@ for name, M, N, K in shapes:
     res = {}
     for rep in range(2):
         res.setdefault("lx2v", []).append(timed(lambda: hip.gemm(a, w, b, out=out)))
+        ws = hip.gemm_workspace_for(a, N, K)   # None where the last round of tiles is not worth a K split
+        if ws is not None:
+            res.setdefault("lx2v + K split of the last round", []).append(timed(lambda: hip.gemm(a, w, b, out=out, workspace=ws)))
         res.setdefault("blas", []).append(timed(lambda: torch.matmul(a, w.t(), out=out)))
     line = f"{name}: "
     for k, v in res.items():
