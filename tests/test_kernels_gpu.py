@@ -250,6 +250,10 @@ def test_gemm_k_split_of_a_sparse_last_round(cuda, M, N, K, epi, options):
     split = run(ws)
     assert torch.equal(run(ws), split)                       # deterministic
     assert torch.equal(run(ws[:need - 16]), plain)           # too small a workspace only switches the split off
+    if epi == "resid":                                       # in place (the Linear plugin's call: out is resid)
+        x = resid.clone()
+        assert hip.gemm(a, w, b, epilogue=hip.EPI_RESIDUAL, resid=x, gate=gate, out=x, workspace=ws) is x
+        assert torch.equal(x, split)
     diff = plain != split
     assert bool(diff.any())                                  # the split is live
     # the differing outputs lie in at most `rem` tiles ...
