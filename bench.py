@@ -532,6 +532,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank == 0:
+        # a sign of life on stderr every 30 s (the one JSON line comes at the very end, minutes into a 20-step run)
+        import threading
+
+        t_start = time.perf_counter()
+
+        def heartbeat():
+            while True:
+                time.sleep(30)
+                print(f"[bench] running, {time.perf_counter() - t_start:.0f} s", file=sys.stderr, flush=True)
+
+        threading.Thread(target=heartbeat, daemon=True).start()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     # LX2V_SHARE_GPU=1 + LX2V_DIST_BACKEND=gloo: functional rehearsal of the N>1 path with every rank
