@@ -394,6 +394,22 @@ int lx2v_gemm_int8(const int8_t* A, int64_t lda, const float* a_scale, const int
                    int64_t N, int64_t K, int epilogue, const uint16_t* resid, int64_t ldr,
                    const float* gate, void* stream);
 
+/* lx2v_gemm_fp8 / lx2v_gemm_int8 with a caller-owned workspace (no counterpart in the reference): as
+ * lx2v_gemm_bf16_ws, a last round of output tiles that would fill at most a quarter of the CUs (K >= 4096) is split
+ * along K over all CUs, raw partial sums in the workspace, a last small launch adding them in a fixed order.  int8:
+ * the partial sums are exact int32, so every output equals the plain call's bit for bit; fp8: the tail tiles'
+ * outputs differ by fp32 summation order.  lx2v_gemm_w8a8_workspace_bytes: what a call of that shape can use (0: no
+ * split); a NULL, misaligned or smaller workspace only switches the split off. */
+int64_t lx2v_gemm_w8a8_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int lx2v_gemm_fp8_ws(const uint8_t* A, int64_t lda, const float* a_scale, const uint8_t* W, int64_t ldw,
+                     const float* w_scale, const float* bias, uint16_t* C, int64_t ldc, int64_t M,
+                     int64_t N, int64_t K, int epilogue, const uint16_t* resid, int64_t ldr,
+                     const float* gate, void* workspace, int64_t workspace_bytes, void* stream);
+int lx2v_gemm_int8_ws(const int8_t* A, int64_t lda, const float* a_scale, const int8_t* W, int64_t ldw,
+                      const float* w_scale, const float* bias, uint16_t* C, int64_t ldc, int64_t M,
+                      int64_t N, int64_t K, int epilogue, const uint16_t* resid, int64_t ldr,
+                      const float* gate, void* workspace, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

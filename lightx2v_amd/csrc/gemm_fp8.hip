@@ -380,7 +380,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_fp8_pp_kernel(const GemmParams 
 
 static int gemm_w8a8(bool int8, const uint8_t* A, int64_t lda, const float* a_scale, const uint8_t* W, int64_t ldw, const float* w_scale,
                      const float* bias, uint16_t* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
-                     const uint16_t* resid, int64_t ldr, const float* gate, void* stream) {
+                     const uint16_t* resid, int64_t ldr, const float* gate, void* workspace, int64_t workspace_bytes, void* stream) {
   LX2V_REQUIRE(M == 0 || (A && W && C && a_scale && w_scale), LX2V_EINVAL, "gemm_fp8: null tensor");
   LX2V_REQUIRE(M >= 0 && N > 0 && K > 0, LX2V_EINVAL, "gemm_fp8: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
   LX2V_REQUIRE(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), LX2V_EUNSUP, "gemm_fp8: dimensions must fit in 31 bits");
@@ -411,7 +411,7 @@ static int gemm_w8a8(bool int8, const uint8_t* A, int64_t lda, const float* a_sc
   // Default (gemm_kernel = 0): the persistent one-wave-per-SIMD kernel.  Its staging addresses rows through
   // 32-bit buffer offsets, so operands whose extent reaches 4 GiB stay with the 8-wave kernels.
   if (lx2v_options().gemm_kernel == 0 && M * lda < (1LL << 32) && N * ldw < (1LL << 32) && ldc < (1LL << 22)) {  // (its stores address one 256-row panel of C with 31 bits)
-    const int rc = lx2v_gemm_w8a8_launch_w4(p, int8, epilogue, st);
+    const int rc = lx2v_gemm_w8a8_launch_w4(p, int8, epilogue, workspace, workspace_bytes, st);
     if (rc != LX2V_OK) return rc;
     LX2V_CHECK_LAUNCH(int8 ? "gemm_int8(w4)" : "gemm_fp8(w4)");
     return LX2V_OK;
@@ -448,12 +448,35 @@ static int gemm_w8a8(bool int8, const uint8_t* A, int64_t lda, const float* a_sc
 extern "C" int lx2v_gemm_fp8(const uint8_t* A, int64_t lda, const float* a_scale, const uint8_t* W, int64_t ldw, const float* w_scale,
                              const float* bias, uint16_t* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
                              const uint16_t* resid, int64_t ldr, const float* gate, void* stream) {
-  return gemm_w8a8(false, A, lda, a_scale, W, ldw, w_scale, bias, C, ldc, M, N, K, epilogue, resid, ldr, gate, stream);
+  return gemm_w8a8(false, A, lda, a_scale, W, ldw, w_scale, bias, C, ldc, M, N, K, epilogue, resid, ldr, gate, nullptr, 0, stream);
 }
 
 extern "C" int lx2v_gemm_int8(const int8_t* A, int64_t lda, const float* a_scale, const int8_t* W, int64_t ldw, const float* w_scale,
                               const float* bias, uint16_t* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
                               const uint16_t* resid, int64_t ldr, const float* gate, void* stream) {
   return gemm_w8a8(true, reinterpret_cast<const uint8_t*>(A), lda, a_scale, reinterpret_cast<const uint8_t*>(W), ldw, w_scale, bias, C, ldc, M, N, K, epilogue,
-                   resid, ldr, gate, stream);
+                   resid, ldr, gate, nullptr, 0, stream);
+}
+
+extern "C" int64_t lx2v_gemm_w8a8_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0 || M >= (1LL << 31) || N >= (1LL << 31) || K >= (1LL << 31) || K % BK != 0) return 0;
+  GemmParams p{};
+  p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  p.tiles_m = (int)((M + BM - 1) / BM);
+  p.tiles_n = (int)((N + BN - 1) / BN);
+  if ((int64_t)p.tiles_m * p.tiles_n >= (1LL << 31) || lx2v_options().gemm_kernel != 0) return 0;
+  return lx2v_gemm_w8a8_w4_workspace_bytes(p);
+}
+
+extern "C" int lx2v_gemm_fp8_ws(const uint8_t* A, int64_t lda, const float* a_scale, const uint8_t* W, int64_t ldw, const float* w_scale,
+                                const float* bias, uint16_t* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
+                                const uint16_t* resid, int64_t ldr, const float* gate, void* workspace, int64_t workspace_bytes, void* stream) {
+  return gemm_w8a8(false, A, lda, a_scale, W, ldw, w_scale, bias, C, ldc, M, N, K, epilogue, resid, ldr, gate, workspace, workspace_bytes, stream);
+}
+
+extern "C" int lx2v_gemm_int8_ws(const int8_t* A, int64_t lda, const float* a_scale, const int8_t* W, int64_t ldw, const float* w_scale,
+                                 const float* bias, uint16_t* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
+                                 const uint16_t* resid, int64_t ldr, const float* gate, void* workspace, int64_t workspace_bytes, void* stream) {
+  return gemm_w8a8(true, reinterpret_cast<const uint8_t*>(A), lda, a_scale, reinterpret_cast<const uint8_t*>(W), ldw, w_scale, bias, C, ldc, M, N, K, epilogue,
+                   resid, ldr, gate, workspace, workspace_bytes, stream);
 }

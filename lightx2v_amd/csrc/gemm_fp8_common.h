@@ -22,12 +22,21 @@ struct GemmParams {
   int64_t lda, ldw, ldc, ldr;
   int M, N, K;
   int tiles_m, tiles_n;
+  // Persistent kernel: the tiles it runs (virtual block ids below ntiles_run); the tiles of a sparsely filled last
+  // round [tail_first, tiles_m * tiles_n) go to a second launch that splits their K range into tail_split parts of
+  // tail_nk K-tiles (raw accumulators into `partials` in fragment order: fp32, or the exact int32 sums of int8) and
+  // a third that adds the parts in a fixed order and applies scales and epilogue.
+  int ntiles_run;
+  int tail_first, tail_split, tail_nk;
+  float* partials;
 };
 
 }  // namespace lx2v_w8a8
 
-// The persistent kernel's launcher (gemm_w8a8_w4.hip), for p already validated by gemm_w8a8().
-int lx2v_gemm_w8a8_launch_w4(const lx2v_w8a8::GemmParams& p, bool int8, int epilogue, hipStream_t st);
+// The persistent kernel's launcher (gemm_w8a8_w4.hip), for p already validated by gemm_w8a8(), and the workspace a
+// call of that shape can use (0: its last round is not split).
+int lx2v_gemm_w8a8_launch_w4(lx2v_w8a8::GemmParams& p, bool int8, int epilogue, void* workspace, int64_t workspace_bytes, hipStream_t st);
+int64_t lx2v_gemm_w8a8_w4_workspace_bytes(const lx2v_w8a8::GemmParams& p);
 
 namespace {
 

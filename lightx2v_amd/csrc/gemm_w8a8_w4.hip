@@ -30,6 +30,8 @@
 // eight consecutive columns per lane, 256-byte row segments out), with the two scales applied first:
 // v = acc * a_scale[m] * w_scale[n] + bias, the arithmetic of the 8-wave kernels in gemm_fp8.hip, so
 // results are bit-identical to theirs.
+#include <algorithm>
+
 #include "gemm_fp8_common.h"
 
 namespace {
@@ -38,6 +40,7 @@ namespace {
 #define W8_ABL 0  // timing ablations (wrong results): 1 no LDS-DMA in the loop, 2 no fragment reads, 4 no wait + barrier per K-tile, 8 no epilogue, 16 no MFMAs
 #endif
 constexpr int W4_THREADS = 256;
+constexpr int EPI_PARTIAL = 3;  // kernel instance that leaves the raw accumulators of a K range (internal)
 constexpr int NSLOT = 5;
 constexpr int W4_LDS = NSLOT * TILE_BYTES;  // all 160 KiB of the CU
 constexpr int W4_GROUP_M = 4;               // row panels per column sweep (the bf16 kernel's measured choice)
@@ -108,6 +111,13 @@ LX2V_DEVICE void acc_to_lds(int lds_addr, const f32x4& acc) {
   else asm volatile("ds_write_b128 %0, %1" ::"v"(lds_addr), "v"(acc) : "memory");
 }
 
+// ... or of a global store at `sbase` (wave-uniform) + `voff` bytes.
+template <bool IN_AGPR>
+LX2V_DEVICE void acc_to_global(int voff, const f32x4& acc, uint64_t sbase) {
+  if constexpr (IN_AGPR) asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(voff), "a"(acc), "s"(sbase) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(voff), "v"(acc), "s"(sbase) : "memory");
+}
+
 LX2V_DEVICE u32x4 raw_descriptor(const void* base, int64_t bytes) {
   const uint64_t a = reinterpret_cast<uint64_t>(base);
   u32x4 d;
@@ -128,9 +138,19 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_w8a8_w4_kernel(const GemmPara
   const int wm = wid >> 1, wn = wid & 1;
   const int fr = lane & 15, fq = lane >> 4;
 
-  const int ntiles = p.tiles_m * p.tiles_n;
+  // EPI == EPI_PARTIAL: one workgroup per (tail tile, K range); everything else is the same stream of one item.
+  constexpr bool PARTIAL = EPI == EPI_PARTIAL;
+  const int ntiles = p.ntiles_run;
   const int grid = gridDim.x;
-  const int nk = p.K / BK;
+  int nk = p.K / BK;
+  int part_vbid = 0;    // virtual block id of the partial item's tile
+  int64_t k_first = 0;  // first K byte of the item
+  if constexpr (PARTIAL) {
+    const int item = blockIdx.x, part = item % p.tail_split;
+    part_vbid = p.tail_first + item / p.tail_split;
+    k_first = (int64_t)part * p.tail_nk * BK;
+    nk = min(p.tail_nk, nk - part * p.tail_nk);
+  }
 
   // ---- staging: DMA instruction q (0..7) of wave w fills rows 64 w + 8 q .. + 7 of the tile image
   // (1 KiB of LDS, lane L the 16 bytes at 16 L: row 64 w + 8 q + (L >> 3), position L & 7 holding
@@ -159,12 +179,12 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_w8a8_w4_kernel(const GemmPara
   // DMA instructions of the stream's last two K-tiles fetch nothing and write zeros into a slot
   // nobody reads, so the loop body needs no "last tiles" variants.
   auto d_panel = [&]() __attribute__((always_inline)) {
-    const int vbid = d_ord * grid + (int)blockIdx.x;
-    const bool live = vbid < ntiles;
+    const int vbid = PARTIAL ? part_vbid : d_ord * grid + (int)blockIdx.x;
+    const bool live = PARTIAL ? d_ord == 0 : vbid < ntiles;
     int m0 = 0, n0 = 0;
     if (live) tile_origin_w4(p, vbid, m0, n0);
-    a_rs = raw_descriptor(p.A + (int64_t)m0 * p.lda, live ? ((int64_t)p.M - m0) * p.lda : 0);
-    w_rs = raw_descriptor(p.W + (int64_t)n0 * p.ldw, live ? ((int64_t)p.N - n0) * p.ldw : 0);
+    a_rs = raw_descriptor(p.A + k_first + (int64_t)m0 * p.lda, live ? ((int64_t)p.M - m0) * p.lda - k_first : 0);
+    w_rs = raw_descriptor(p.W + k_first + (int64_t)n0 * p.ldw, live ? ((int64_t)p.N - n0) * p.ldw - k_first : 0);
   };
   d_panel();
   auto dma_m0 = [&](uint32_t slot_base, auto dstc) __attribute__((always_inline)) {
@@ -435,8 +455,23 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_w8a8_w4_kernel(const GemmPara
     });
   };
 
+  // ---- a partial item's result: the raw accumulators, tuple by tuple in fragment order (1 KiB per wave and tuple) ----
+  auto store_partial = [&]() __attribute__((always_inline)) {
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");  // the last MFMAs were issued a few cycles ago
+    const float* base = p.partials + ((int64_t)blockIdx.x * 4 + wid) * (64 * 64 * 4);
+    const uint64_t bu = reinterpret_cast<uint64_t>(base);
+    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)bu), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(bu >> 32));
+    const uint64_t sbase = ((uint64_t)bhi << 32) | blo;
+    static_for<0, 8>([&](auto ntc) __attribute__((always_inline)) {
+      static_for<0, 8>([&](auto mtc) __attribute__((always_inline)) {
+        constexpr int nt = decltype(ntc)::value, mt = decltype(mtc)::value;
+        acc_to_global<acc_in_agpr(nt, mt)>(lane * 16 + (nt * 8 + mt) * 1024, acc[nt][mt], sbase);
+      });
+    });
+  };
+
   // ---- prologue: half-tiles 0..3 (K-tiles 0 and 1 of the stream), then A[0..7], W[0], W[1] of K-tile 0 ----
-  const int my_tiles = (int)blockIdx.x < ntiles ? (ntiles - 1 - (int)blockIdx.x) / grid + 1 : 0;
+  const int my_tiles = PARTIAL ? 1 : (int)blockIdx.x < ntiles ? (ntiles - 1 - (int)blockIdx.x) / grid + 1 : 0;
   const int64_t total = (int64_t)my_tiles * nk;  // K-tiles in this workgroup's stream
   if (total == 0) return;
   static_for<0, 2>([&](auto tc) __attribute__((always_inline)) {
@@ -475,6 +510,10 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_w8a8_w4_kernel(const GemmPara
     else ktile(IntC<0>{}, sa, sw, sa1, sw1, sfree, false);
     relaxed = false;
     if (++kt == nk) {
+      if constexpr (PARTIAL) {
+        store_partial();
+        break;
+      }
       int m0, n0;
       tile_origin_w4(p, ord * grid + (int)blockIdx.x, m0, n0);
       relaxed = !(W8_ABL & 8);
@@ -497,10 +536,82 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_w8a8_w4_kernel(const GemmPara
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may still be writing this workgroup's LDS when it ends
 }
 
-}  // namespace
+// Tail tiles of a launch whose last round was split along K: one thread adds the parts of 8 consecutive outputs of a
+// row in a fixed order (int8: exact int32 sums, so the result equals the unsplit kernel's bit for bit; fp8: fp32 sums
+// in another order) and applies scales and epilogue with the persistent kernel's arithmetic.
+template <int EPI, bool INT8>
+__global__ __launch_bounds__(256) void gemm_w8a8_tail_fixup_kernel(const GemmParams p) {
+  const int t = blockIdx.x >> 5;  // tail tile
+  const int e = ((blockIdx.x & 31) << 8) + threadIdx.x;
+  const int r = e & 255, c = (e >> 8) * 8;  // consecutive threads: consecutive rows (consecutive lanes of a fragment)
+  int m0, n0;
+  tile_origin_w4(p, p.tail_first + t, m0, n0);
+  const int gm = m0 + r, gn = n0 + c;
+  if (gm >= p.M || gn >= p.N) return;
+  const int wave = (r >> 7) * 2 + (c >> 7), mt = (r & 127) >> 4, fr = r & 15, nt = (c & 127) >> 4, fq0 = (c & 15) >> 2;
+  const float* src = p.partials + ((((int64_t)t * p.tail_split * 4 + wave) * 64 + nt * 8 + mt) * 64 + fq0 * 16 + fr) * 4;
+  const int64_t part_stride = (int64_t)4 * 64 * 64 * 4;  // floats per item
+  float v[8];
+  if constexpr (INT8) {
+    int acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int part = 0; part < p.tail_split; ++part) {
+      const i32x4 lo = *reinterpret_cast<const i32x4*>(src + part * part_stride);
+      const i32x4 hi = *reinterpret_cast<const i32x4*>(src + part * part_stride + 64);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { acc[j] += lo[j]; acc[4 + j] += hi[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)acc[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    for (int part = 0; part < p.tail_split; ++part) {
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(src + part * part_stride);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(src + part * part_stride + 64);  // the next column group: 16 lanes on
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] += lo[j]; v[4 + j] += hi[j]; }
+    }
+  }
+  const float sa = p.a_scale[gm];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float bv = p.bias != nullptr ? p.bias[gn + j] : 0.f;
+    const float gv = (EPI == LX2V_EPI_RESIDUAL && p.gate != nullptr) ? p.gate[gn + j] : 1.f;
+    v[j] = dequant_bias(v[j], sa, p.w_scale[gn + j], bv);
+    if (EPI == LX2V_EPI_GELU_TANH) v[j] = gelu_tanh(v[j]);
+    if (EPI == LX2V_EPI_RESIDUAL) v[j] *= gv;
+  }
+  if (EPI == LX2V_EPI_RESIDUAL) {
+    float y[8];
+    unpack8(*reinterpret_cast<const u32x4*>(p.resid + (int64_t)gm * p.ldr + gn), y);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)(__bf16)v[j] + y[j];
+  }
+  *reinterpret_cast<u32x4*>(p.C + (int64_t)gm * p.ldc + gn) = pack8(v);
+}
 
-// One workgroup per CU (the 160 KiB of LDS allow no second one), never more than there are tiles.
-int lx2v_gemm_w8a8_launch_w4(const lx2v_w8a8::GemmParams& p, bool int8, int epilogue, hipStream_t st) {
+struct TailPlan {
+  int rem, split, nk_part;
+  int64_t bytes;
+};
+
+// Is the last round of one tile per CU worth splitting along K?  Only when at most a quarter of the CUs would
+// have a tile in it and K is long enough for two more launches to pay.
+TailPlan tail_plan(const GemmParams& p, int cus) {
+  TailPlan t{0, 1, 0, 0};
+  const int64_t ntiles = (int64_t)p.tiles_m * p.tiles_n;
+  const int nk = p.K / BK;
+  if (ntiles <= cus || nk < 64) return t;  // (K = 5120: a round is 68 us long and the split breaks even, measured)
+  const int rem = (int)(ntiles % cus);
+  if (rem == 0 || rem * 4 > cus) return t;
+  int split = std::min(cus / rem, 16);
+  const int per = (nk + split - 1) / split;
+  split = (nk + per - 1) / per;  // as many parts as are not empty
+  t = TailPlan{rem, split, per, (int64_t)rem * split * 4 * 64 * 64 * 4 * (int64_t)sizeof(float)};
+  return t;
+}
+
+int device_cus() {
   static int cus_cached[64];
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
@@ -510,20 +621,44 @@ int lx2v_gemm_w8a8_launch_w4(const lx2v_w8a8::GemmParams& p, bool int8, int epil
     }
     cus = cus_cached[dev];
   }
-  const int64_t ntiles = (int64_t)p.tiles_m * p.tiles_n;
-  const dim3 grid((unsigned)(ntiles < cus ? ntiles : cus)), block(W4_THREADS);
-  if (int8) {
-    switch (epilogue) {
-      case LX2V_EPI_NONE: hipLaunchKernelGGL((gemm_w8a8_w4_kernel<LX2V_EPI_NONE, true>), grid, block, 0, st, p); break;
-      case LX2V_EPI_GELU_TANH: hipLaunchKernelGGL((gemm_w8a8_w4_kernel<LX2V_EPI_GELU_TANH, true>), grid, block, 0, st, p); break;
-      default: hipLaunchKernelGGL((gemm_w8a8_w4_kernel<LX2V_EPI_RESIDUAL, true>), grid, block, 0, st, p); break;
-    }
-  } else {
-    switch (epilogue) {
-      case LX2V_EPI_NONE: hipLaunchKernelGGL((gemm_w8a8_w4_kernel<LX2V_EPI_NONE, false>), grid, block, 0, st, p); break;
-      case LX2V_EPI_GELU_TANH: hipLaunchKernelGGL((gemm_w8a8_w4_kernel<LX2V_EPI_GELU_TANH, false>), grid, block, 0, st, p); break;
-      default: hipLaunchKernelGGL((gemm_w8a8_w4_kernel<LX2V_EPI_RESIDUAL, false>), grid, block, 0, st, p); break;
-    }
+  return cus;
+}
+
+template <bool INT8>
+void launch_all(GemmParams& p, int epilogue, const TailPlan& tp, int cus, hipStream_t st) {
+  const dim3 grid((unsigned)(p.ntiles_run < cus ? p.ntiles_run : cus)), block(W4_THREADS);
+  switch (epilogue) {
+    case LX2V_EPI_NONE: hipLaunchKernelGGL((gemm_w8a8_w4_kernel<LX2V_EPI_NONE, INT8>), grid, block, 0, st, p); break;
+    case LX2V_EPI_GELU_TANH: hipLaunchKernelGGL((gemm_w8a8_w4_kernel<LX2V_EPI_GELU_TANH, INT8>), grid, block, 0, st, p); break;
+    default: hipLaunchKernelGGL((gemm_w8a8_w4_kernel<LX2V_EPI_RESIDUAL, INT8>), grid, block, 0, st, p); break;
   }
+  if (tp.rem == 0) return;
+  hipLaunchKernelGGL((gemm_w8a8_w4_kernel<EPI_PARTIAL, INT8>), dim3((unsigned)(tp.rem * tp.split)), block, 0, st, p);
+  const dim3 fgrid((unsigned)(tp.rem * 32));
+  switch (epilogue) {
+    case LX2V_EPI_NONE: hipLaunchKernelGGL((gemm_w8a8_tail_fixup_kernel<LX2V_EPI_NONE, INT8>), fgrid, dim3(256), 0, st, p); break;
+    case LX2V_EPI_GELU_TANH: hipLaunchKernelGGL((gemm_w8a8_tail_fixup_kernel<LX2V_EPI_GELU_TANH, INT8>), fgrid, dim3(256), 0, st, p); break;
+    default: hipLaunchKernelGGL((gemm_w8a8_tail_fixup_kernel<LX2V_EPI_RESIDUAL, INT8>), fgrid, dim3(256), 0, st, p); break;
+  }
+}
+
+}  // namespace
+
+int64_t lx2v_gemm_w8a8_w4_workspace_bytes(const lx2v_w8a8::GemmParams& p) { return tail_plan(p, device_cus()).bytes; }
+
+// One workgroup per CU (the 160 KiB of LDS allow no second one), never more than there are tiles.  With a
+// workspace, a sparsely filled last round becomes a K split of its tiles (see GemmParams).
+int lx2v_gemm_w8a8_launch_w4(lx2v_w8a8::GemmParams& p, bool int8, int epilogue, void* workspace, int64_t workspace_bytes, hipStream_t st) {
+  const int cus = device_cus();
+  const int64_t ntiles = (int64_t)p.tiles_m * p.tiles_n;
+  TailPlan tp = tail_plan(p, cus);
+  if (tp.bytes == 0 || workspace == nullptr || (reinterpret_cast<uintptr_t>(workspace) & 15u) != 0 || workspace_bytes < tp.bytes) tp = TailPlan{0, 1, 0, 0};
+  p.ntiles_run = (int)(ntiles - tp.rem);
+  p.tail_first = p.ntiles_run;
+  p.tail_split = tp.split;
+  p.tail_nk = tp.nk_part;
+  p.partials = reinterpret_cast<float*>(workspace);
+  if (int8) launch_all<true>(p, epilogue, tp, cus, st);
+  else launch_all<false>(p, epilogue, tp, cus, st);
   return LX2V_OK;
 }

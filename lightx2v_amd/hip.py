@@ -65,6 +65,9 @@ _SIGNATURES = {
     "lx2v_quant_int8_rowwise": [_P, _I64, _P, _I64, _P, _I64, _I, _I, _P],
     "lx2v_quant_int8_rowwise_kseg": [_P, _I64, _P, _P, _I64, _P, _I64, _I, _P],
     "lx2v_gemm_int8": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _P, _I64, _P, _P],
+    "lx2v_gemm_fp8_ws": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _P, _I64, _P, _P, _I64, _P],
+    "lx2v_gemm_int8_ws": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _P, _I64, _P, _P, _I64, _P],
+    "lx2v_gemm_w8a8_workspace_bytes": [_I64, _I64, _I64],
 }
 EXPORTS = tuple(_SIGNATURES) + ("lx2v_abi_version", "lx2v_last_error")
 
@@ -88,7 +91,7 @@ def load() -> ctypes.CDLL:
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_int64 if name in ("lx2v_attn_fp8_workspace_bytes", "lx2v_attn_fp8_static_bytes", "lx2v_attn_bf16_workspace_bytes", "lx2v_gemm_bf16_workspace_bytes") else ctypes.c_int
+        fn.restype = ctypes.c_int64 if name in ("lx2v_attn_fp8_workspace_bytes", "lx2v_attn_fp8_static_bytes", "lx2v_attn_bf16_workspace_bytes", "lx2v_gemm_bf16_workspace_bytes", "lx2v_gemm_w8a8_workspace_bytes") else ctypes.c_int
     lib.lx2v_abi_version.restype = ctypes.c_int
     lib.lx2v_last_error.restype = ctypes.c_char_p
     _lib = lib
@@ -695,15 +698,35 @@ def dequant_fp8_rowwise(q: torch.Tensor, scale: torch.Tensor, out: Optional[torc
     return out
 
 
+def gemm_w8a8_workspace_bytes(M: int, N: int, K: int) -> int:
+    """Bytes of partial sums `gemm_fp8` / `gemm_int8` can use for a call of this shape (0: no K split of the last round)."""
+    return int(load().lx2v_gemm_w8a8_workspace_bytes(int(M), int(N), int(K)))
+
+
+def gemm_w8a8_workspace_for(a8: torch.Tensor, N: int, K: int) -> Optional[torch.Tensor]:
+    """The device's shared GEMM workspace (see `gemm_workspace_for`) when this W8A8 product would use one."""
+    need = gemm_w8a8_workspace_bytes(a8.shape[0], N, K)
+    if need == 0:
+        return None
+    ws = _GEMM_WORKSPACES.get(a8.device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=a8.device)
+        _GEMM_WORKSPACES[a8.device] = ws
+    return ws
+
+
 def gemm_int8(a8: torch.Tensor, a_scale: torch.Tensor, w8: torch.Tensor, w_scale: torch.Tensor, bias=None, epilogue: int = EPI_NONE,
-              resid: Optional[torch.Tensor] = None, gate=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              resid: Optional[torch.Tensor] = None, gate=None, out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
     """(a8 [M,K] int8) @ (w8 [N,K] int8)^T, exact in int32, scaled per row / per output channel -> bf16 [M,N]."""
-    return gemm_fp8(a8, a_scale, w8, w_scale, bias, epilogue, resid, gate, out, _dtype=torch.int8)
+    return gemm_fp8(a8, a_scale, w8, w_scale, bias, epilogue, resid, gate, out, workspace, _dtype=torch.int8)
 
 
 def gemm_fp8(a8: torch.Tensor, a_scale: torch.Tensor, w8: torch.Tensor, w_scale: torch.Tensor, bias=None, epilogue: int = EPI_NONE,
-             resid: Optional[torch.Tensor] = None, gate=None, out: Optional[torch.Tensor] = None, _dtype=torch.float8_e4m3fn) -> torch.Tensor:
-    """(a8 [M,K] e4m3) @ (w8 [N,K] e4m3)^T scaled per row / per output channel -> bf16 [M,N]."""
+             resid: Optional[torch.Tensor] = None, gate=None, out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None,
+             _dtype=torch.float8_e4m3fn) -> torch.Tensor:
+    """(a8 [M,K] e4m3) @ (w8 [N,K] e4m3)^T scaled per row / per output channel -> bf16 [M,N].
+    `workspace`: optional uint8 GPU tensor (`gemm_w8a8_workspace_bytes`) for the K split of a sparsely filled last round
+    of output tiles (fp8: those tiles' outputs differ by fp32 summation order; int8: bit-identical)."""
     for n, t in (("a8", a8), ("w8", w8)):
         if not t.is_cuda or t.dtype != _dtype or t.stride(-1) != 1:
             raise Lx2vError(f"gemm_fp8: {n} must be a GPU {_dtype} tensor with a contiguous inner dimension")
@@ -723,8 +746,11 @@ def gemm_fp8(a8: torch.Tensor, a_scale: torch.Tensor, w8: torch.Tensor, w_scale:
         _need_out("gemm_fp8.resid", resid, (M, N), a8)
     elif epilogue == EPI_RESIDUAL:
         raise Lx2vError("gemm_fp8: the residual epilogue needs `resid`")
-    entry = "lx2v_gemm_int8" if _dtype == torch.int8 else "lx2v_gemm_fp8"
+    if workspace is not None and (workspace.dtype != torch.uint8 or workspace.device != a8.device or not workspace.is_contiguous()):
+        raise Lx2vError("gemm_fp8: workspace must be a contiguous uint8 tensor on the operands' device")
+    entry = "lx2v_gemm_int8_ws" if _dtype == torch.int8 else "lx2v_gemm_fp8_ws"
     st = getattr(load(), entry)(a8.data_ptr(), a8.stride(0), a_scale.data_ptr(), w8.data_ptr(), w8.stride(0), w_scale.data_ptr(), _ptr(bias),
-                                out.data_ptr(), out.stride(0), M, N, K, epilogue, _ptr(resid), 0 if resid is None else resid.stride(0), _ptr(gate), _stream())
+                                out.data_ptr(), out.stride(0), M, N, K, epilogue, _ptr(resid), 0 if resid is None else resid.stride(0), _ptr(gate),
+                                _ptr(workspace), 0 if workspace is None else workspace.numel(), _stream())
     _check(st, entry)
     return out

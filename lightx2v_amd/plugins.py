@@ -376,7 +376,7 @@ class HipFp8MMWeight(HipMMWeight):
         else:
             xq, xs = hip.quant_fp8_rowwise(x, kseg=kseg, dim=self.weight_nk.shape[1])
         return hip.gemm_fp8(xq, xs, self.weight_nk, self.weight_scale, self.bias, epilogue=epilogue, resid=resid, gate=gate,
-                            out=resid if epilogue == hip.EPI_RESIDUAL else out)
+                            out=resid if epilogue == hip.EPI_RESIDUAL else out, workspace=hip.gemm_w8a8_workspace_for(xq, *self.weight_nk.shape))
 
     def apply(self, input_tensor, out=None):
         return self._run(input_tensor, hip.EPI_NONE, out=out)
@@ -425,7 +425,7 @@ class HipInt8MMWeight(HipFp8MMWeight):
     def _run(self, x, epilogue, resid=None, gate=None, out=None, kseg=None):
         xq, xs = hip.quant_int8_rowwise(x, kseg=kseg, dim=self.weight_nk.shape[1])
         return hip.gemm_int8(xq, xs, self.weight_nk, self.weight_scale, self.bias, epilogue=epilogue, resid=resid, gate=gate,
-                             out=resid if epilogue == hip.EPI_RESIDUAL else out)
+                             out=resid if epilogue == hip.EPI_RESIDUAL else out, workspace=hip.gemm_w8a8_workspace_for(xq, *self.weight_nk.shape))
 
 
 # ----------------------------------------------------------------------------------- norms

@@ -258,3 +258,65 @@ def test_fp8_weight_quantised_from_fp32_rows(cuda):
     mm = L.MM_WEIGHT_REGISTER["hip-fp8"]("w.weight", None)
     mm.load({"w.weight": w.to(cuda)})
     assert torch.equal(mm.weight_scale.cpu(), s_ref) and torch.equal(mm.weight_nk.cpu().view(torch.uint8), q_ref.view(torch.uint8))
+
+
+@pytest.mark.parametrize("int8", [False, True])
+@pytest.mark.parametrize("M,N,K,epi", [(4352, 4096, 8192, "none"),      # 272 tiles: one round + 16, split 16 ways (4 K-tiles each)
+                                       (4300, 4104, 8320, "gelu"),      # ragged last row panel / column, 65 K-tiles -> 13 parts of 5
+                                       (75600, 5120, 13824, "resid")])  # 14B FFN-2: 23 rounds + 32 tiles, 8 parts of 14 K-tiles (the last of 10)
+def test_gemm_w8a8_k_split_of_a_sparse_last_round(cuda, M, N, K, epi, int8, options):
+    """With a workspace the tiles of a sparsely filled last round are split along K over all CUs and a fix-up launch
+    adds the raw partial sums in a fixed order before scales and epilogue.  int8: the partial sums are exact, so the
+    whole output equals the plain call's bit for bit.  fp8: the tail tiles differ by fp32 summation order only."""
+    g = torch.Generator(device=cuda).manual_seed(80 + M % 89)
+    a = torch.randn(M, K, generator=g, device=cuda, dtype=torch.float32).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g, device=cuda, dtype=torch.float32) * 0.05).to(torch.bfloat16)
+    quant = hip.quant_int8_rowwise if int8 else hip.quant_fp8_rowwise
+    gemm = hip.gemm_int8 if int8 else hip.gemm_fp8
+    aq, a_s = quant(a)
+    wq, w_s = quant(w)
+    del a, w
+    bias = torch.randn(N, generator=g, device=cuda) * 0.1
+    gate = torch.randn(N, generator=g, device=cuda)
+    resid = torch.randn(M, N, generator=g, device=cuda, dtype=torch.float32).to(torch.bfloat16) if epi == "resid" else None
+    options(gemm_kernel=0)
+    need = hip.gemm_w8a8_workspace_bytes(M, N, K)
+    rem = (-(-M // 256) * -(-N // 256)) % 256
+    assert need > 0 and need % (rem * 256 * 256 * 4) == 0
+    ws = torch.empty(need, dtype=torch.uint8, device=cuda)
+
+    def run(workspace):
+        if epi == "gelu":
+            return gemm(aq, a_s, wq, w_s, bias, epilogue=hip.EPI_GELU_TANH, workspace=workspace)
+        if epi == "resid":
+            return gemm(aq, a_s, wq, w_s, bias, epilogue=hip.EPI_RESIDUAL, resid=resid.clone(), gate=gate, workspace=workspace)
+        return gemm(aq, a_s, wq, w_s, bias, workspace=workspace)
+
+    plain = run(None)
+    ws.fill_(0x5A)
+    split = run(ws)
+    assert bool((ws != 0x5A).any())                          # the split is live: partial sums were written
+    assert torch.equal(run(ws), split)                       # deterministic
+    ws.fill_(0x5A)
+    assert torch.equal(run(ws[:need - 16]), plain)           # too small a workspace only switches the split off ...
+    assert bool((ws == 0x5A).all())                          # ... and is not touched
+    if int8:
+        assert torch.equal(split, plain)
+        return
+    # (sums of e4m3 products are often exact in fp32, so the two orders can agree in every bit)
+    diff = plain != split
+    pad = torch.zeros(-(-M // 256) * 256, -(-N // 256) * 256, dtype=torch.bool, device=cuda)
+    pad[:M, :N] = diff
+    touched = pad.view(-(-M // 256), 256, -(-N // 256), 256).any(dim=3).any(dim=1)
+    assert int(touched.sum()) <= rem, (int(touched.sum()), rem)
+    assert (plain.float() - split.float()).abs().max().item() <= 2.0 ** -7 * plain.float().abs().max().item()   # one bf16 step
+    assert int(diff.sum()) <= 0.02 * rem * 65536
+
+
+def test_gemm_w8a8_workspace_query(cuda, options):
+    options(gemm_kernel=0)
+    assert hip.gemm_w8a8_workspace_bytes(75600, 5120, 13824) == 32 * 8 * 256 * 256 * 4
+    assert hip.gemm_w8a8_workspace_bytes(75600, 15360, 13824) == 0     # last round 96 tiles
+    assert hip.gemm_w8a8_workspace_bytes(75600, 5120, 5120) == 0       # K too short: a round of 40 K-tiles is over before two more launches pay
+    options(gemm_kernel=1)
+    assert hip.gemm_w8a8_workspace_bytes(75600, 5120, 13824) == 0

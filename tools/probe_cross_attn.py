@@ -14,7 +14,12 @@ def timed(fn, iters=20):
     for _ in range(iters): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
-for kern in (16, 16, 4, 8, 16):
+for rs in (1, 0, 1, 0):
+    hip.set_option("attn_kernel", 16); hip.set_option("attn_qb", 0); hip.set_option("attn_round_sync", rs)
+    ms = timed(lambda: hip.attn_fwd(q, k, v))
+    print(f"round_sync {rs}: {ms:.3f} ms", flush=True)
+hip.set_option("attn_round_sync", 1)
+for kern in (16,):
     for qb in ((0, 5, 4) if kern == 16 else (0,)):
         hip.set_option("attn_kernel", kern); hip.set_option("attn_qb", qb)
         ms = timed(lambda: hip.attn_fwd(q, k, v))
