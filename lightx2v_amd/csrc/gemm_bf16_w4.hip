@@ -542,6 +542,7 @@ __global__ __launch_bounds__(256) void gemm_tail_fixup_kernel(const GemmParams p
   const float* src = p.partials + ((((int64_t)t * p.tail_split * 4 + wave) * 64 + nt * 8 + mt) * 64 + fq0 * 16 + fr) * 4;
   const int64_t part_stride = (int64_t)4 * 64 * 64 * 4;  // floats per item
   float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
   for (int part = 0; part < p.tail_split; ++part) {
     const f32x4 lo = *reinterpret_cast<const f32x4*>(src + part * part_stride);
     const f32x4 hi = *reinterpret_cast<const f32x4*>(src + part * part_stride + 64);  // the next column group: 16 lanes on

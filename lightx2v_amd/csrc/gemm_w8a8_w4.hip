@@ -554,7 +554,8 @@ __global__ __launch_bounds__(256) void gemm_w8a8_tail_fixup_kernel(const GemmPar
   float v[8];
   if constexpr (INT8) {
     int acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int part = 0; part < p.tail_split; ++part) {
+  #pragma unroll 4
+  for (int part = 0; part < p.tail_split; ++part) {
       const i32x4 lo = *reinterpret_cast<const i32x4*>(src + part * part_stride);
       const i32x4 hi = *reinterpret_cast<const i32x4*>(src + part * part_stride + 64);
 #pragma unroll
@@ -565,7 +566,8 @@ __global__ __launch_bounds__(256) void gemm_w8a8_tail_fixup_kernel(const GemmPar
   } else {
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = 0.f;
-    for (int part = 0; part < p.tail_split; ++part) {
+  #pragma unroll 4
+  for (int part = 0; part < p.tail_split; ++part) {
       const f32x4 lo = *reinterpret_cast<const f32x4*>(src + part * part_stride);
       const f32x4 hi = *reinterpret_cast<const f32x4*>(src + part * part_stride + 64);  // the next column group: 16 lanes on
 #pragma unroll
