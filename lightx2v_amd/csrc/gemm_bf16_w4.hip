@@ -52,7 +52,7 @@ namespace {
 #define W4_DMA_GROUPS 2  // the 8 DMA pieces of a half-step go to MFMA groups 0, D, 2 D, ... (1: the first half of the step, 2: spread over all of it)
 #endif
 #ifndef W4_ABL
-#define W4_ABL 0  // timing ablations (wrong results): 1 no LDS-DMA in the loop, 2 no fragment reads, 4 no wait + barrier per K-tile, 8 no epilogue, 16 no MFMAs, 32 wait for the DMA only (no barrier), 64 barrier only (no waits), 128 no relaxed wait behind an epilogue, 256 every workgroup stages tile (0, 0) (all L2 hits), 512 the epilogue computes but does not store
+#define W4_ABL 0  // timing ablations (wrong results; 1024: with 8 only, half as many MFMAs of the 32x32x16 shape): 1 no LDS-DMA in the loop, 2 no fragment reads, 4 no wait + barrier per K-tile, 8 no epilogue, 16 no MFMAs, 32 wait for the DMA only (no barrier), 64 barrier only (no waits), 128 no relaxed wait behind an epilogue, 256 every workgroup stages tile (0, 0) (all L2 hits), 512 the epilogue computes but does not store
 #endif
 constexpr int W4_THREADS = 256;
 constexpr int EPI_PARTIAL = 3;                // kernel instance that leaves raw fp32 accumulators of a K range (internal)
@@ -97,6 +97,20 @@ template <bool IN_AGPR>
 LX2V_DEVICE void acc_to_global(int voff, const f32x4& acc, uint64_t sbase) {
   if constexpr (IN_AGPR) asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(voff), "a"(acc), "s"(sbase) : "memory");
   else asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(voff), "v"(acc), "s"(sbase) : "memory");
+}
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+// (timing build only: named accumulator registers, which the compiler is told are clobbered -- with tied 16-register
+// operands it copies the tuples around in front of every MFMA)
+template <int B>
+LX2V_DEVICE void mfma_big(const u32x4& wf, const u32x4& af) {
+  if constexpr (B == 0) asm volatile("v_mfma_f32_32x32x16_bf16 a[0:15], %0, %1, a[0:15]" ::"v"(wf), "v"(af) : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15");
+  if constexpr (B == 1) asm volatile("v_mfma_f32_32x32x16_bf16 a[16:31], %0, %1, a[16:31]" ::"v"(wf), "v"(af) : "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31");
+  if constexpr (B == 2) asm volatile("v_mfma_f32_32x32x16_bf16 a[32:47], %0, %1, a[32:47]" ::"v"(wf), "v"(af) : "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
+  if constexpr (B == 3) asm volatile("v_mfma_f32_32x32x16_bf16 a[48:63], %0, %1, a[48:63]" ::"v"(wf), "v"(af) : "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63");
+  if constexpr (B == 4) asm volatile("v_mfma_f32_32x32x16_bf16 a[64:79], %0, %1, a[64:79]" ::"v"(wf), "v"(af) : "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79");
+  if constexpr (B == 5) asm volatile("v_mfma_f32_32x32x16_bf16 a[80:95], %0, %1, a[80:95]" ::"v"(wf), "v"(af) : "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95");
+  if constexpr (B == 6) asm volatile("v_mfma_f32_32x32x16_bf16 a[96:111], %0, %1, a[96:111]" ::"v"(wf), "v"(af) : "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111");
+  if constexpr (B == 7) asm volatile("v_mfma_f32_32x32x16_bf16 a[112:127], %0, %1, a[112:127]" ::"v"(wf), "v"(af) : "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127");
 }
 template <int NT, int MT>
 LX2V_DEVICE void pin_acc(f32x4& acc) {
@@ -267,13 +281,15 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_bf16_w4_kernel(const GemmPara
       constexpr int q = g / W4_DMA_GROUPS;
       // One instruction class per MFMA shadow: M0, the DMA instruction, then one fragment read each
       // (a wave alone on its SIMD issues about one instruction every four cycles, so an MFMA covers three).
-      mfma_acc<acc_in_agpr(nt, mt0), FIRST>(acc[nt][mt0], cur.w[nt], cur.a[mt0]);
+      if constexpr (W4_ABL & 1024) mfma_big<((nt >> 1) * 4 + (mt0 >> 1)) % 8>(cur.w[nt], cur.a[mt0]);
+      else mfma_acc<acc_in_agpr(nt, mt0), FIRST>(acc[nt][mt0], cur.w[nt], cur.a[mt0]);
       if constexpr (DMA) dma_piece_m0(dslot, IntC<q>{});
       __builtin_amdgcn_sched_barrier(0);
-      mfma_acc<acc_in_agpr(nt, mt0 + 1), FIRST>(acc[nt][mt0 + 1], cur.w[nt], cur.a[mt0 + 1]);
+      if constexpr (!(W4_ABL & 1024)) mfma_acc<acc_in_agpr(nt, mt0 + 1), FIRST>(acc[nt][mt0 + 1], cur.w[nt], cur.a[mt0 + 1]);
       if constexpr (DMA) dma_piece_go(HALFc, IntC<q>{});
       __builtin_amdgcn_sched_barrier(0);
-      mfma_acc<acc_in_agpr(nt, mt0 + 2), FIRST>(acc[nt][mt0 + 2], cur.w[nt], cur.a[mt0 + 2]);
+      if constexpr (W4_ABL & 1024) mfma_big<((nt >> 1) * 4 + ((mt0 + 2) >> 1)) % 8>(cur.w[nt], cur.a[mt0 + 2]);
+      else mfma_acc<acc_in_agpr(nt, mt0 + 2), FIRST>(acc[nt][mt0 + 2], cur.w[nt], cur.a[mt0 + 2]);
       if constexpr (W4_ABL & 2) {
       } else if constexpr (g < 4) {
         nxt.a[2 * g] = read_frag(na, 2 * g);
@@ -281,7 +297,7 @@ __global__ __launch_bounds__(W4_THREADS) void gemm_bf16_w4_kernel(const GemmPara
         nxt.w[2 * g - 8] = read_frag(nw, 2 * g - 8);
       }
       __builtin_amdgcn_sched_barrier(0);
-      mfma_acc<acc_in_agpr(nt, mt0 + 3), FIRST>(acc[nt][mt0 + 3], cur.w[nt], cur.a[mt0 + 3]);
+      if constexpr (!(W4_ABL & 1024)) mfma_acc<acc_in_agpr(nt, mt0 + 3), FIRST>(acc[nt][mt0 + 3], cur.w[nt], cur.a[mt0 + 3]);
       if constexpr (W4_ABL & 2) {
       } else if constexpr (g < 4) {
         nxt.a[2 * g + 1] = read_frag(na, 2 * g + 1);
